@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Build libhode.so (gfx950) in-tree with hipcc: `python build_hip.py [-j N] [--force]`."""
+import argparse
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(ROOT, "hybrid-ode-neurips-2021_amd", "csrc")
+OUT = os.path.join(ROOT, "hybrid-ode-neurips-2021_amd", "hode", "libhode.so")
+OBJ = os.path.join(CSRC, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-variable",
+         "-Wno-unused-but-set-variable"]
+RK_DIMS = (4, 6, 8, 12, 20)
+
+
+def units():
+    u = [("hode_api", os.path.join(CSRC, "hode_api.hip"), [])]
+    for d in RK_DIMS:
+        u.append(("hode_rk_d%d" % d, os.path.join(CSRC, "hode_rk_dim.hip"), ["-DHODE_DIM=%d" % d]))
+    for name in ("hode_dopri5", "hode_lstm"):
+        src = os.path.join(CSRC, name + ".hip")
+        if os.path.exists(src):
+            u.append((name, src, []))
+    return u
+
+
+def newest_dep():
+    ts = [os.path.getmtime(os.path.join(ROOT, "include", "hode.h")), os.path.getmtime(__file__)]
+    for f in os.listdir(CSRC):
+        if f.endswith((".hpp", ".hip", ".h")):
+            ts.append(os.path.getmtime(os.path.join(CSRC, f)))
+    return max(ts)
+
+
+def compile_one(name, src, extra, force, dep_time):
+    obj = os.path.join(OBJ, name + ".o")
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= dep_time:
+        return name, 0.0, ""
+    t0 = time.time()
+    cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (name, " ".join(cmd), r.stderr[-6000:]))
+    return name, time.time() - t0, r.stderr
+
+
+def build(jobs=6, force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    dep = newest_dep()
+    us = units()
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        futs = [ex.submit(compile_one, n, s, e, force, dep) for n, s, e in us]
+        for f in futs:
+            name, dt, err = f.result()
+            if verbose and dt:
+                print("  hipcc %-14s %.1fs" % (name, dt), flush=True)
+            if verbose and err.strip():
+                print(err[-2000:], file=sys.stderr)
+    objs = [os.path.join(OBJ, n + ".o") for n, _, _ in us]
+    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(o) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        if verbose:
+            print("  linked", os.path.relpath(OUT, ROOT), flush=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-j", type=int, default=6)
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    build(a.j, a.force)

@@ -1,0 +1,168 @@
+// C-ABI entry points of libhode.so (declared in include/hode.h): argument checks, variant selection, launches.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "hode_host.hpp"
+#include "hode_roche.hpp"
+
+namespace hode {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static int hip_fail(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+// out[j] += sum over waves of partials[w][j], in wave order (deterministic)
+__global__ void fold_partials_kernel(const float* __restrict__ partials, int n_waves, int P, int n_w, int n_b,
+                                     float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gth,
+                                     int need_th) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = 0;
+  for (; w + 3 < n_waves; w += 4) {
+    s0 += partials[(size_t)w * P + j];
+    s1 += partials[(size_t)(w + 1) * P + j];
+    s2 += partials[(size_t)(w + 2) * P + j];
+    s3 += partials[(size_t)(w + 3) * P + j];
+  }
+  for (; w < n_waves; ++w) s0 += partials[(size_t)w * P + j];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (j < n_w) {
+    if (gw) gw[j] += s;
+  } else if (j < n_w + n_b) {
+    if (gb) gb[j - n_w] += s;
+  } else if (need_th && gth) {
+    gth[j - n_w - n_b] += s;
+  }
+}
+
+
+}  // namespace hode
+
+namespace {
+
+using hode::RkArgs;
+using hode::RkLaunch;
+
+int n_waves_for(int B, int lpp) { return (int)(((long long)B * lpp + 63) / 64); }
+
+// LPP = 4 (a patient per DPP quad, 16 patients per wave) fills the chip at the 10k-patient shape; LPP = 1 has
+// the lowest total instruction count and wins once every SIMD has >= 2 waves without splitting patients
+// (256 CUs x 4 SIMDs x 2 waves x 64 lanes = 131072 patients).
+int choose_lpp(const hode_solve_desc* d) {
+  const int M = d->latent_dim - 4;
+  const bool can4 = M > 0 && M % 4 == 0;
+  if (d->lanes_per_patient == 1) return 1;
+  if (d->lanes_per_patient == 4) return can4 ? 4 : 1;
+  if (!can4) return 1;
+  return d->batch >= 131072 ? 1 : 4;
+}
+
+int n_partials(const hode_solve_desc* d) {
+  const int M = d->latent_dim - 4;
+  return M * d->latent_dim + M + hode::kNTheta;
+}
+
+RkArgs make_args(const hode_solve_desc* d) {
+  RkArgs a{};
+  a.t = d->t; a.y0 = d->y0; a.dosage = d->dosage; a.dose_times = d->dose_times; a.theta = d->theta;
+  a.w1 = d->w1; a.b1 = d->b1; a.h = d->h; a.grad_h = d->grad_h; a.grad_y0 = d->grad_y0;
+  a.partials = (float*)d->workspace; a.status = d->status;
+  a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
+  return a;
+}
+
+int dispatch_dim(const hode_solve_desc* d, bool bwd, hipStream_t s) {
+  RkLaunch L;
+  L.method = d->method;
+  L.lpp = choose_lpp(d);
+  L.ablate = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
+  L.bwd = bwd;
+  L.need_th = d->need_theta_grad != 0;
+  const RkArgs a = make_args(d);
+  switch (d->latent_dim) {
+    case 4: return hode::rk_dispatch_d4(L, a, s);
+    case 6: return hode::rk_dispatch_d6(L, a, s);
+    case 8: return hode::rk_dispatch_d8(L, a, s);
+    case 12: return hode::rk_dispatch_d12(L, a, s);
+    case 20: return hode::rk_dispatch_d20(L, a, s);
+  }
+  return hode::fail(HODE_E_UNSUPPORTED, "latent_dim %d has no compiled kernel (have 4, 6, 8, 12, 20)", d->latent_dim);
+}
+
+int check_rk(const hode_solve_desc* d, bool bwd) {
+  if (!d) return hode::fail(HODE_E_NULL, "descriptor is NULL");
+  if (d->struct_size != sizeof(hode_solve_desc))
+    return hode::fail(HODE_E_SIZE, "struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(hode_solve_desc));
+  if (d->rhs_kind != HODE_RHS_ROCHE && d->rhs_kind != HODE_RHS_ROCHE_ABLATE)
+    return hode::fail(HODE_E_UNSUPPORTED, "rhs_kind %d is not handled by the fixed-grid Roche kernels", d->rhs_kind);
+  if (d->method < HODE_METHOD_EULER || d->method > HODE_METHOD_RK4_38)
+    return hode::fail(HODE_E_UNSUPPORTED, "unknown fixed-grid method %d", d->method);
+  if (d->batch <= 0 || d->n_times <= 0 || d->latent_dim < 4 || d->n_dose < 0)
+    return hode::fail(HODE_E_SIZE, "bad sizes: batch=%d n_times=%d latent_dim=%d n_dose=%d", d->batch, d->n_times,
+                      d->latent_dim, d->n_dose);
+  if (!d->t || !d->y0 || !d->dosage || !d->theta || !d->h || (d->n_dose > 0 && !d->dose_times))
+    return hode::fail(HODE_E_NULL, "t / y0 / dosage / dose_times / theta / h must be non-NULL");
+  if (d->latent_dim > 4 && (!d->w1 || !d->b1)) return hode::fail(HODE_E_NULL, "w1 / b1 required when latent_dim > 4");
+  if (bwd && (!d->grad_h || !d->grad_y0)) return hode::fail(HODE_E_NULL, "grad_h / grad_y0 required by the backward");
+  if (d->latent_dim % 4 == 0) {
+    uintptr_t m = (uintptr_t)d->y0 | (uintptr_t)d->h;
+    if (bwd) m |= (uintptr_t)d->grad_h | (uintptr_t)d->grad_y0;
+    if (m & 15) return hode::fail(HODE_E_ALIGN, "y0 / h / grad_h / grad_y0 must be 16-byte aligned");
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int hode_version(void) { return HODE_ABI_VERSION; }
+
+extern "C" const char* hode_last_error_string(void) { return hode::g_err; }
+
+extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
+  if (!d || d->struct_size != sizeof(hode_solve_desc)) return 0;
+  switch (which) {
+    case HODE_WS_RK_FWD: return 0;
+    case HODE_WS_RK_BWD: return (size_t)n_waves_for(d->batch, choose_lpp(d)) * n_partials(d) * sizeof(float);
+    default: return 0;
+  }
+}
+
+extern "C" int hode_rk_fwd(const hode_solve_desc* d, void* stream) {
+  if (int e = check_rk(d, false)) return e;
+  return dispatch_dim(d, false, (hipStream_t)stream);
+}
+
+extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
+  if (int e = check_rk(d, true)) return e;
+  const size_t need = hode_workspace_bytes(d, HODE_WS_RK_BWD);
+  if (!d->workspace || d->workspace_bytes < need)
+    return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = dispatch_dim(d, true, s)) return e;
+  const int M = d->latent_dim - 4;
+  const int P = n_partials(d);
+  const int nw = n_waves_for(d->batch, choose_lpp(d));
+  hipLaunchKernelGGL(hode::fold_partials_kernel, dim3((P + 63) / 64), dim3(64), 0, s, (const float*)d->workspace, nw, P,
+                     M * d->latent_dim, M, d->grad_w1, d->grad_b1, d->grad_theta, d->need_theta_grad);
+  return hode::hip_fail(hipGetLastError(), "fold_partials launch");
+}
+
+// not built yet: declared in include/hode.h so the ABI is stable, they report HODE_E_UNSUPPORTED
+extern "C" int hode_dopri5_fwd(const hode_solve_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_dopri5_fwd: not built yet"); }
+extern "C" int hode_dopri5_bwd(const hode_solve_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_dopri5_bwd: not built yet"); }
+extern "C" size_t hode_lstm_workspace_bytes(const hode_lstm_desc*) { return 0; }
+extern "C" int hode_lstm_fwd(const hode_lstm_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_fwd: not built yet"); }
+extern "C" int hode_lstm_bwd(const hode_lstm_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_bwd: not built yet"); }

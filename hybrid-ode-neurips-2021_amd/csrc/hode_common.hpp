@@ -1,0 +1,106 @@
+// Device-side helpers shared by the hode kernels (gfx950 only: wave64, DPP, v_exp/v_rcp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HODE_DEV __device__ __forceinline__
+
+namespace hode {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------------------------
+// transcendental helpers.  Accuracy targets are stated per function and checked in tests/test_hip_math.py.
+// ---------------------------------------------------------------------------------------------------------
+
+// exp(x) for the dose decay: |x| is bounded by kel * t_max (tens), 2-ulp v_exp_f32 after a split multiply so
+// that the argument reduction does not lose bits for |x| up to ~80.
+HODE_DEV float exp_f32(float x) {
+  // x*log2(e) in two pieces (hi product + fma correction), then hardware exp2
+  const float l2e = 1.4426950408889634f;
+  float hi = x * l2e;
+  float lo = __builtin_fmaf(x, l2e, -hi) + x * 1.925963033500011e-08f;  // log2e - (float)log2e
+  float r = __builtin_rintf(hi);
+  float f = (hi - r) + lo;
+  float e = __builtin_amdgcn_exp2f(f);
+  return __builtin_amdgcn_ldexpf(e, (int)r);  // ldexp handles over/underflow to inf / 0
+}
+
+// tanh(x): odd polynomial x + x^3 P(x^2) for |x| < 0.625 (own minimax fit, 1.3 ulp), 1 - 2/(exp(2|x|)+1) above
+// (<= 3 ulp, absolute error <= 1.2e-7).  NaN propagates, +-inf -> +-1.
+HODE_DEV float tanh_f32(float x) {
+  float ax = __builtin_fabsf(x);
+  float u = x * x;
+  float p = -0.005508354399353266f;
+  p = __builtin_fmaf(p, u, 0.020461998879909515f);
+  p = __builtin_fmaf(p, u, -0.05368518456816673f);
+  p = __builtin_fmaf(p, u, 0.13330785930156708f);
+  p = __builtin_fmaf(p, u, -0.3333325684070587f);
+  float small = __builtin_fmaf(ax * u, p, ax);
+  float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);  // exp(2|x|)
+  float big = __builtin_fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
+  float r = ax < 0.625f ? small : big;
+  return __builtin_copysignf(r, x);
+}
+
+// logistic sigmoid via tanh: sigma(x) = 0.5 + 0.5 tanh(x/2)
+HODE_DEV float sigmoid_f32(float x) { return __builtin_fmaf(tanh_f32(0.5f * x), 0.5f, 0.5f); }
+
+// IEEE-correct-ish division (v_rcp + one Newton step; result within 1 ulp for normal operands)
+HODE_DEV float div_f32(float a, float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  float q = a * r;
+  float e = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(e, r, q);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cross-lane helpers for the "4 lanes per patient" layout: a patient occupies one DPP quad.
+// ---------------------------------------------------------------------------------------------------------
+
+// broadcast the value held by lane SRC (0..3) of each quad to all four lanes of the quad (one v_mov_dpp)
+template <int SRC>
+HODE_DEV float quad_bcast(float v) {
+  constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);  // quad_perm:[SRC,SRC,SRC,SRC]
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+}
+
+// sum over the four lanes of each quad, result in all four lanes (two DPP adds)
+HODE_DEV float quad_sum(float v) {
+  // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E
+  float a = v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  return a + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xf, 0xf, true));
+}
+
+// sum across the lanes of a wave that hold the same quad position (xor over lane bits 2..5), result everywhere
+HODE_DEV float wave_sum_stride4(float v) {
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// full wave sum, result in every lane
+HODE_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+HODE_DEV float nextafter_up(float x) {
+  // nextafter(x, +inf) for finite x (torchdiffeq Perturb.NEXT, oracle/solvers.py::_nextafter)
+  if (x == 0.0f) return __builtin_bit_cast(float, 1u);
+  uint32_t u = __builtin_bit_cast(uint32_t, x);
+  return __builtin_bit_cast(float, x > 0.0f ? u + 1u : u - 1u);
+}
+HODE_DEV float nextafter_down(float x) {
+  if (x == 0.0f) return __builtin_bit_cast(float, 0x80000001u);
+  uint32_t u = __builtin_bit_cast(uint32_t, x);
+  return __builtin_bit_cast(float, x > 0.0f ? u - 1u : u + 1u);
+}
+
+// fp32 ops that must NOT be contracted into an fma (stage times are compared against dose times with >= / ==,
+// so they have to round exactly like the reference's separate mul and add)
+HODE_DEV float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+HODE_DEV float add_rn(float a, float b) { return __fadd_rn(a, b); }
+
+}  // namespace hode

@@ -1,0 +1,42 @@
+// Host-side declarations shared by the translation units of libhode.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/hode.h"
+
+namespace hode {
+
+// records a thread-local message (returned by hode_last_error_string) and returns `code`
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// kernel arguments of the fixed-grid Roche kernels (device pointers + sizes), see hode_rk_kernels.hpp
+struct RkArgs {
+  const float* __restrict__ t;
+  const float* __restrict__ y0;
+  const float* __restrict__ dosage;
+  const float* __restrict__ dose_times;
+  const float* __restrict__ theta;
+  const float* __restrict__ w1;
+  const float* __restrict__ b1;
+  float* __restrict__ h;
+  const float* __restrict__ grad_h;
+  float* __restrict__ grad_y0;
+  float* __restrict__ partials;  // [n_waves][P] per-wave parameter-gradient partials (backward)
+  int* __restrict__ status;
+  int B, T, K, perturb;
+};
+
+struct RkLaunch {
+  int method;   // HODE_METHOD_*
+  int lpp;      // lanes per patient: 1 or 4
+  bool ablate, bwd, need_th;
+};
+
+// one entry per compiled latent dimension (hode_rk_dim.hip is compiled once per -DHODE_DIM=<D>)
+int rk_dispatch_d4(const RkLaunch&, const RkArgs&, hipStream_t);
+int rk_dispatch_d6(const RkLaunch&, const RkArgs&, hipStream_t);
+int rk_dispatch_d8(const RkLaunch&, const RkArgs&, hipStream_t);
+int rk_dispatch_d12(const RkLaunch&, const RkArgs&, hipStream_t);
+int rk_dispatch_d20(const RkLaunch&, const RkArgs&, hipStream_t);
+
+}  // namespace hode

@@ -1,0 +1,404 @@
+// Fixed-grid solve (euler / midpoint / 3/8-rule rk4) of the hybrid Roche ODE and its discrete adjoint, gfx950.
+//
+// Replaces torchdiffeq.odeint(method in {"euler","midpoint","rk4"}) as called at reference model.py:1116 with
+// func = RocheODE (model.py:446-555), and the autograd replay of those ops in loss.backward()
+// (training_utils.py:50).  CPU restatement: oracle/solvers.py::_odeint_fixed + oracle/rhs.py::RocheRHS.
+//
+// One launch integrates the whole time grid.  Data layout in HBM is the reference's own: h[T][B][D] time-major
+// fp32, so a wave's store at step n covers one contiguous run of (patients per wave) * D * 4 bytes.
+//   forward : reads y0 (4D B/patient), dose time+amount (8 B), writes h (4TD B)          -> 4TD + 4D + 8
+//   backward: reads h and grad_h (8TD B), writes grad_y0 (4D B)                           -> 8TD + 4D
+//   parameters (<= 15 + (D-4)(D+1) floats) live in SGPRs/VGPRs; per-wave gradient partials go to a
+//   [waves][P] scratch that a second tiny kernel folds in a fixed order (deterministic, no float atomics).
+// The kernels are VALU/latency bound, not HBM bound ("Roofline"): state, stages, weights and
+// gradient accumulators all stay in registers for the whole sweep.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/hode.h"
+#include "hode_host.hpp"
+#include "hode_roche.hpp"
+
+namespace hode {
+
+
+constexpr float kOneThird = (float)(1.0 / 3.0);
+constexpr float kTwoThirds = (float)(2.0 / 3.0);
+
+template <int D>
+HODE_DEV void load_vec(const float* __restrict__ p, float (&v)[D]) {
+  if constexpr (D % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+      const float4 x = reinterpret_cast<const float4*>(p)[c];
+      v[4 * c] = x.x; v[4 * c + 1] = x.y; v[4 * c + 2] = x.z; v[4 * c + 3] = x.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; ++i) v[i] = p[i];
+  }
+}
+
+// store the state of one patient; with LPP = 4 the four lanes share the chunks (one 16-byte store per lane)
+template <int D, int LPP>
+HODE_DEV void store_vec(float* __restrict__ p, const float (&v)[D], int q, bool live) {
+  if (!live) return;
+  if constexpr (D % 4 == 0) {
+    constexpr int NC = D / 4;
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += LPP) {
+      float4 x = make_float4(v[4 * c0], v[4 * c0 + 1], v[4 * c0 + 2], v[4 * c0 + 3]);
+      int c = c0;
+      if constexpr (LPP > 1) {
+#pragma unroll
+        for (int qq = 1; qq < LPP; ++qq) {
+          if (c0 + qq < NC) {
+            const bool m = (q == qq);
+            x.x = m ? v[4 * (c0 + qq)] : x.x;
+            x.y = m ? v[4 * (c0 + qq) + 1] : x.y;
+            x.z = m ? v[4 * (c0 + qq) + 2] : x.z;
+            x.w = m ? v[4 * (c0 + qq) + 3] : x.w;
+          }
+        }
+        c = c0 + q;
+      }
+      if (c < NC) reinterpret_cast<float4*>(p)[c] = x;
+    }
+  } else {
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) p[i] = v[i];
+    }
+  }
+}
+
+template <int LPP>
+struct LaneMap {
+  int p, q;
+  bool live;
+  HODE_DEV LaneMap(int B) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pp = gid / LPP;
+    q = gid % LPP;
+    live = pp < B;
+    p = live ? pp : B - 1;  // idle lanes shadow the last patient so that cross-lane ops stay well defined
+  }
+};
+
+HODE_DEV DoseSched load_dose(const RkArgs& a, int p) {
+  DoseSched ds;
+  ds.dosage = a.dosage[p];
+  ds.K = a.K;
+  ds.taus = a.dose_times + (size_t)p * a.K;
+  ds.tau0 = a.K == 1 ? ds.taus[0] : 0.f;
+  return ds;
+}
+
+// stage times of one step, rounded exactly like the fp32 tensor ops of the reference solver
+struct StageTimes {
+  float t0, t1, dt, ta, tb, t_first, t_last;
+  HODE_DEV StageTimes(const float* __restrict__ t, int n, int perturb, int method) {
+    t0 = t[n];
+    t1 = t[n + 1];
+    dt = t1 - t0;
+    t_first = perturb ? nextafter_up(t0) : t0;
+    t_last = perturb ? nextafter_down(t1) : t1;
+    if (method == HODE_METHOD_RK4_38) {
+      ta = add_rn(t0, mul_rn(dt, kOneThird));
+      tb = add_rn(t0, mul_rn(dt, kTwoThirds));
+    } else {
+      ta = add_rn(t0, mul_rn(0.5f, dt));
+      tb = ta;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int D, int LPP, int METHOD, bool ABLATE, bool HILL2>
+HODE_DEV void rk_fwd_body(const RkArgs& a) {
+  using Ml = MlSlice<D, LPP>;
+  constexpr int MR = Ml::MR;
+  const LaneMap<LPP> lm(a.B);
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  Ml ml;
+  ml.load(a.w1, a.b1, lm.q);
+  const DoseSched ds = load_dose(a, lm.p);
+
+  float y[D];
+  load_vec<D>(a.y0 + (size_t)lm.p * D, y);
+  const size_t row = (size_t)a.B * D;
+  float* hp = a.h + (size_t)lm.p * D;
+  store_vec<D, LPP>(hp, y, lm.q, lm.live);
+
+  float own[MR];
+  for (int n = 0; n + 1 < a.T; ++n) {
+    const StageTimes st(a.t, n, a.perturb, METHOD);
+    float k1[D];
+    roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, ds.at(st.t_first, th.kel), y, k1, own);
+    if constexpr (METHOD == HODE_METHOD_EULER) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) y[i] = __builtin_fmaf(st.dt, k1[i], y[i]);
+    } else if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
+      float Y2[D], k2[D];
+      const float half = 0.5f * st.dt;
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y2[i] = __builtin_fmaf(k1[i], half, y[i]);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, ds.at(st.ta, th.kel), Y2, k2, own);
+#pragma unroll
+      for (int i = 0; i < D; ++i) y[i] = __builtin_fmaf(st.dt, k2[i], y[i]);
+    } else {
+      float Y[D], k2[D], k3[D], k4[D];
+      const float dt = st.dt;
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y[i] = __builtin_fmaf(dt * k1[i], kOneThird, y[i]);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, ds.at(st.ta, th.kel), Y, k2, own);
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y[i] = __builtin_fmaf(dt, __builtin_fmaf(-k1[i], kOneThird, k2[i]), y[i]);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, ds.at(st.tb, th.kel), Y, k3, own);
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y[i] = __builtin_fmaf(dt, (k1[i] - k2[i]) + k3[i], y[i]);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, ds.at(st.t_last, th.kel), Y, k4, own);
+      const float w = dt * 0.125f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) y[i] = __builtin_fmaf((k1[i] + 3.0f * (k2[i] + k3[i])) + k4[i], w, y[i]);
+    }
+    hp += row;
+    store_vec<D, LPP>(hp, y, lm.q, lm.live);
+  }
+  if (a.status) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < D; ++i) bad |= !__builtin_isfinite(y[i]);
+    if (bad && lm.live) atomicOr(a.status, HODE_STATUS_NONFINITE);
+  }
+}
+
+template <int D, int LPP, int METHOD, bool ABLATE>
+__global__ __launch_bounds__(64) void rk_fwd_kernel(RkArgs a) {
+  // Hill exponents are 2.0 in every shipped configuration (sim_config.py:5-6) and never optimised
+  // (run_simulation.py:125-129): x*x fast path, wave-uniform branch to the general powf path otherwise.
+  const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
+  if (hill2) rk_fwd_body<D, LPP, METHOD, ABLATE, true>(a);
+  else rk_fwd_body<D, LPP, METHOD, ABLATE, false>(a);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Discrete adjoint.  For step n (walked n = T-2 .. 0) the stage states are recomputed from the stored h[n]
+// (no stage tape in HBM), then the step is differentiated in reverse:
+//   rk4 3/8:  y' = y + dt/8 (k1 + 3k2 + 3k3 + k4),  Y2 = y + dt/3 k1,  Y3 = y + dt (k2 - k1/3),  Y4 = y + dt (k1 - k2 + k3)
+//   g4 = dt/8 l';  a4 = J4^T g4;  g3 = 3dt/8 l' + dt a4;  a3 = J3^T g3;  g2 = 3dt/8 l' - dt a4 + dt a3;  a2 = J2^T g2;
+//   g1 = dt/8 l' + dt a4 - dt/3 a3 + dt/3 a2;  a1 = J1^T g1;  l = l' + a1 + a2 + a3 + a4 (+ grad_h[n]).
+template <int D, int LPP>
+constexpr int n_partials() { return (D - 4) * D + (D - 4) + kNTheta; }
+
+template <int D, int LPP, int METHOD, bool ABLATE, bool HILL2, bool NEED_TH>
+HODE_DEV void rk_bwd_body(const RkArgs& a) {
+  using Ml = MlSlice<D, LPP>;
+  constexpr int MR = Ml::MR;
+  constexpr int M = D - 4;
+  const LaneMap<LPP> lm(a.B);
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  Ml ml;
+  ml.load(a.w1, a.b1, lm.q);
+  const DoseSched ds = load_dose(a, lm.p);
+  GradAcc<D, LPP> acc;
+  acc.zero();
+
+  const size_t row = (size_t)a.B * D;
+  const float* hp = a.h + (size_t)(a.T - 1) * row + (size_t)lm.p * D;
+  const float* gp = a.grad_h + (size_t)(a.T - 1) * row + (size_t)lm.p * D;
+  const float live = lm.live ? 1.0f : 0.0f;
+
+  float lam[D];
+  load_vec<D>(gp, lam);
+#pragma unroll
+  for (int i = 0; i < D; ++i) lam[i] *= live;
+
+  float y[D], gh[D];
+  if (a.T > 1) {
+    load_vec<D>(hp - row, y);
+    load_vec<D>(gp - row, gh);
+  }
+  for (int n = a.T - 2; n >= 0; --n) {
+    hp -= row;
+    gp -= row;
+    // prefetch the operands of the next (earlier) step while this one computes
+    float y_nx[D], gh_nx[D];
+    if (n > 0) {
+      load_vec<D>(hp - row, y_nx);
+      load_vec<D>(gp - row, gh_nx);
+    }
+    const StageTimes st(a.t, n, a.perturb, METHOD);
+    const float dt = st.dt;
+    float k1[D], s1[MR], a_[D], g[D];
+    const float dose1 = ds.at(st.t_first, th.kel);
+    roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dose1, y, k1, s1);
+    if constexpr (METHOD == HODE_METHOD_EULER) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) g[i] = dt * lam[i];
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, ds, st.t_first, dose1, y, s1, g, lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) lam[i] += a_[i];
+    } else if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
+      float Y2[D], k2[D], s2[MR];
+      const float half = 0.5f * dt;
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y2[i] = __builtin_fmaf(k1[i], half, y[i]);
+      const float dose2 = ds.at(st.ta, th.kel);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dose2, Y2, k2, s2);
+#pragma unroll
+      for (int i = 0; i < D; ++i) g[i] = dt * lam[i];
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, ds, st.ta, dose2, Y2, s2, g, lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        lam[i] += a_[i];
+        g[i] = half * a_[i];
+      }
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, ds, st.t_first, dose1, y, s1, g, lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) lam[i] += a_[i];
+    } else {
+      float Y2[D], Y3[D], Y4[D], k2[D], k3[D], k4[D], s2[MR], s3[MR], s4[MR];
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y2[i] = __builtin_fmaf(dt * k1[i], kOneThird, y[i]);
+      const float dose2 = ds.at(st.ta, th.kel);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dose2, Y2, k2, s2);
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y3[i] = __builtin_fmaf(dt, __builtin_fmaf(-k1[i], kOneThird, k2[i]), y[i]);
+      const float dose3 = ds.at(st.tb, th.kel);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dose3, Y3, k3, s3);
+#pragma unroll
+      for (int i = 0; i < D; ++i) Y4[i] = __builtin_fmaf(dt, (k1[i] - k2[i]) + k3[i], y[i]);
+      const float dose4 = ds.at(st.t_last, th.kel);
+      roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dose4, Y4, k4, s4);  // only s4 is needed (k4 is dead code)
+
+      const float w1 = dt * 0.125f, w3 = dt * 0.375f;
+      float g1[D], g2[D];
+      // stage 4
+#pragma unroll
+      for (int i = 0; i < D; ++i) g[i] = w1 * lam[i];
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, ds, st.t_last, dose4, Y4, s4, g, lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float da = dt * a_[i];
+        g1[i] = __builtin_fmaf(w1, lam[i], da);
+        g2[i] = __builtin_fmaf(w3, lam[i], -da);
+        g[i] = __builtin_fmaf(w3, lam[i], da);
+        lam[i] += a_[i];
+      }
+      // stage 3
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, ds, st.tb, dose3, Y3, s3, g, lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float da = dt * a_[i];
+        g2[i] += da;
+        g1[i] = __builtin_fmaf(-kOneThird, da, g1[i]);
+        lam[i] += a_[i];
+      }
+      // stage 2
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, ds, st.ta, dose2, Y2, s2, g2, lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        g1[i] = __builtin_fmaf(kOneThird, dt * a_[i], g1[i]);
+        lam[i] += a_[i];
+      }
+      // stage 1
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, ds, st.t_first, dose1, y, s1, g1, lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) lam[i] += a_[i];
+    }
+    // cotangent of the output sample at t_n
+#pragma unroll
+    for (int i = 0; i < D; ++i) lam[i] = __builtin_fmaf(gh[i], live, lam[i]);
+    if (n > 0) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        y[i] = y_nx[i];
+        gh[i] = gh_nx[i];
+      }
+    }
+  }
+  if (a.T == 1) { /* lam already = grad_h[0] */ }
+  store_vec<D, LPP>(a.grad_y0 + (size_t)lm.p * D, lam, lm.q, lm.live);
+
+  // ---- fold the per-lane parameter gradients over the patients of this wave, one partial row per wave
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  float* out = a.partials + (size_t)wave * n_partials<D, LPP>();
+  if constexpr (M > 0) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float s = (LPP == 4) ? wave_sum_stride4(acc.dw[r][i]) : wave_sum(acc.dw[r][i]);
+        if (lane < LPP) out[(lane * MR + r) * D + i] = s;
+      }
+      const float sb = (LPP == 4) ? wave_sum_stride4(acc.db[r]) : wave_sum(acc.db[r]);
+      if (lane < LPP) out[M * D + lane * MR + r] = sb;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kNTheta; ++i) {
+    // every lane of a patient holds the same expert gradient: count quad position 0 only
+    float v = NEED_TH ? acc.dth[i] : 0.f;
+    if constexpr (LPP == 4) v = wave_sum_stride4(v);
+    else v = wave_sum(v);
+    if (lane == 0) out[M * D + M + i] = v;
+  }
+}
+
+template <int D, int LPP, int METHOD, bool ABLATE, bool NEED_TH>
+__global__ __launch_bounds__(64) void rk_bwd_kernel(RkArgs a) {
+  const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
+  if (hill2) rk_bwd_body<D, LPP, METHOD, ABLATE, true, NEED_TH>(a);
+  else rk_bwd_body<D, LPP, METHOD, ABLATE, false, NEED_TH>(a);
+}
+
+}  // namespace hode
+
+
+// ---------------------------------------------------------------------------------------------- launch helpers
+namespace hode {
+
+inline int n_waves_for(int B, int lpp) { return (int)(((long long)B * lpp + 63) / 64); }
+
+template <int D, int LPP, int METHOD, bool ABLATE>
+int launch_fwd(const RkArgs& a, hipStream_t s) {
+  const int nw = n_waves_for(a.B, LPP);
+  hipLaunchKernelGGL((rk_fwd_kernel<D, LPP, METHOD, ABLATE>), dim3(nw), dim3(64), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+template <int D, int LPP, int METHOD, bool ABLATE>
+int launch_bwd(const RkArgs& a, bool need_th, hipStream_t s) {
+  const int nw = n_waves_for(a.B, LPP);
+  if (need_th) hipLaunchKernelGGL((rk_bwd_kernel<D, LPP, METHOD, ABLATE, true>), dim3(nw), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((rk_bwd_kernel<D, LPP, METHOD, ABLATE, false>), dim3(nw), dim3(64), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+template <int D, int LPP, bool ABLATE>
+int dispatch_method(const RkLaunch& L, const RkArgs& a, hipStream_t s) {
+  switch (L.method) {
+    case HODE_METHOD_EULER:
+      return L.bwd ? launch_bwd<D, LPP, HODE_METHOD_EULER, ABLATE>(a, L.need_th, s)
+                   : launch_fwd<D, LPP, HODE_METHOD_EULER, ABLATE>(a, s);
+    case HODE_METHOD_MIDPOINT:
+      return L.bwd ? launch_bwd<D, LPP, HODE_METHOD_MIDPOINT, ABLATE>(a, L.need_th, s)
+                   : launch_fwd<D, LPP, HODE_METHOD_MIDPOINT, ABLATE>(a, s);
+    case HODE_METHOD_RK4_38:
+      return L.bwd ? launch_bwd<D, LPP, HODE_METHOD_RK4_38, ABLATE>(a, L.need_th, s)
+                   : launch_fwd<D, LPP, HODE_METHOD_RK4_38, ABLATE>(a, s);
+  }
+  return fail(HODE_E_UNSUPPORTED, "unknown fixed-grid method %d", L.method);
+}
+
+template <int D>
+int dispatch_lpp(const RkLaunch& L, const RkArgs& a, hipStream_t s) {
+  if constexpr (D > 4 && (D - 4) % 4 == 0) {
+    if (L.lpp == 4) return L.ablate ? dispatch_method<D, 4, true>(L, a, s) : dispatch_method<D, 4, false>(L, a, s);
+  }
+  return L.ablate ? dispatch_method<D, 1, true>(L, a, s) : dispatch_method<D, 1, false>(L, a, s);
+}
+
+}  // namespace hode

@@ -1,0 +1,184 @@
+/*
+ * hode.h -- C ABI of libhode.so: MI355X (gfx950) kernels for the hybrid-ODE hot path.
+ *
+ * The reference (ZhaozhiQIAN/Hybrid-ODE-NeurIPS-2021) has no FFI layer of its own; the operator
+ * boundary of the path is two Python call sites, and every entry point below replaces one of them:
+ *
+ *   torchdiffeq.odeint(func, y0, t, rtol, atol, method, options)   reference model.py:1116, :837, :842
+ *       func = RocheODE.forward      model.py:515-555   (HODE_RHS_ROCHE / HODE_RHS_ROCHE_ABLATE)
+ *       func = NeuralODE.forward     model.py:1019-1026 (HODE_RHS_NEURAL)
+ *       func = RocheODEReal.forward  model.py:613-645   (HODE_RHS_ROCHE_REAL)
+ *     -> hode_rk_fwd / hode_rk_bwd          (method in {"euler","midpoint","rk4"})
+ *     -> hode_dopri5_fwd / hode_dopri5_bwd  (method "dopri5", the reference default, sim_config.py:50)
+ *     The backward entry points replace autograd's replay of the solver ops triggered by
+ *     loss.backward() at reference training_utils.py:50 (the reference imports plain odeint, model.py:9-10,
+ *     so its gradient is the discrete adjoint of the RK scheme, which is what *_bwd compute).
+ *
+ *   nn.LSTM(input_dim, hidden_dim)(obs, hidden) stepped over the window        reference model.py:420-422
+ *     -> hode_lstm_fwd / hode_lstm_bwd      (masked, reverse- or forward-time single-layer LSTM)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer owned by the caller
+ *     unless named host_*.  All floating-point buffers are fp32 (reference global_config.py:3).
+ *   - time-major layouts exactly as the reference holds them: h[T][B][D], action/x/mask [T][B][.]
+ *   - no allocation, no stream synchronisation and no global mutable state inside the library (the only
+ *     exception: hode_dopri5_fwd reads back one 32-byte controller record per chunk of attempts, because
+ *     the number of adaptive steps is data dependent; it says so below).  One call = launches on
+ *     exactly the given stream.  Calls are thread-safe.
+ *   - return value: 0 ok; <0 argument error (HODE_E_*); >0 a hipError_t from a launch.
+ *     hode_last_error_string() returns a thread-local description of the last non-zero return.
+ *   - numerical failure (non-finite state, dt underflow) is reported through desc->status, a device int32
+ *     word the caller zeroes: bit 0 non-finite state, bit 1 dt underflow, bit 2 max_steps exceeded.
+ *     The Python wrapper turns it into RuntimeError so that reference training_utils.py:43-47 keeps working.
+ */
+#ifndef HODE_H_
+#define HODE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HODE_ABI_VERSION 1
+
+/* right-hand side kinds */
+#define HODE_RHS_ROCHE 0        /* expert PK/PD block + tanh(W y + b)          model.py:515-555 */
+#define HODE_RHS_ROCHE_ABLATE 1 /* linear-oscillator expert block (ablate=True) model.py:545-549 */
+#define HODE_RHS_NEURAL 2       /* tanh(W2 tanh(W1 [y,Dose] + b1) + b2)          model.py:1019-1026 */
+#define HODE_RHS_ROCHE_REAL 3   /* two small MLPs + GRU-ODE block                model.py:613-645 */
+
+/* fixed-grid methods (torchdiffeq names "euler", "midpoint", "rk4" = 3/8 rule) */
+#define HODE_METHOD_EULER 0
+#define HODE_METHOD_MIDPOINT 1
+#define HODE_METHOD_RK4_38 2
+
+/* argument errors */
+#define HODE_E_NULL -1      /* a required pointer is NULL */
+#define HODE_E_SIZE -2      /* struct_size mismatch / non-positive dimension */
+#define HODE_E_UNSUPPORTED -3 /* (rhs_kind, latent_dim, method) combination has no kernel */
+#define HODE_E_WORKSPACE -4 /* workspace too small (see hode_workspace_bytes) */
+#define HODE_E_ALIGN -5     /* pointer not 16-byte aligned where the kernel needs it */
+
+/* status word bits (device int32, OR-ed by the kernels) */
+#define HODE_STATUS_NONFINITE 1
+#define HODE_STATUS_DT_UNDERFLOW 2
+#define HODE_STATUS_MAX_STEPS 4
+
+/* layout of theta for HODE_RHS_ROCHE: creation order of the 13 scalars at reference model.py:468-482 */
+enum {
+  HODE_TH_HILL_CURE = 0, HODE_TH_HILL_PATHO, HODE_TH_EC50_PATHO, HODE_TH_EMAX_PATHO, HODE_TH_K_DEXA,
+  HODE_TH_K_DISCURE_IMMUNEREACT, HODE_TH_K_DISCURE_IMMUNITY, HODE_TH_K_DISPROG, HODE_TH_K_IMMUNE_DISEASE,
+  HODE_TH_K_IMMUNE_FEEDBACK, HODE_TH_K_IMMUNE_OFF, HODE_TH_K_IMMUNITY, HODE_TH_KEL,
+  HODE_TH_THETA_1, HODE_TH_THETA_2, /* ablate only, model.py:484-485 */
+  HODE_N_THETA = 16
+};
+
+/*
+ * One descriptor for every solver entry point (fixed-grid and adaptive, forward and backward).
+ * Unused pointers may be NULL.  "acc" = accumulator the caller zero-fills; the kernels add into it.
+ */
+typedef struct hode_solve_desc {
+  uint32_t struct_size;   /* = sizeof(hode_solve_desc) */
+  int32_t rhs_kind;       /* HODE_RHS_* */
+  int32_t method;         /* HODE_METHOD_* (ignored by dopri5 entry points) */
+  int32_t perturb;        /* torchdiffeq options["perturb"] (only DecoderReal sets it, model.py:826) */
+  int32_t batch;          /* B patients */
+  int32_t latent_dim;     /* D = 4 expert + (D-4) learned */
+  int32_t n_times;        /* T = len(t) */
+  int32_t n_dose;         /* K doses per patient (ROCHE / NEURAL), equal for all patients (model.py:507) */
+  int32_t hidden_dim;     /* NEURAL: 10*D; ROCHE_REAL: MLP hidden width */
+  int32_t n_action_times; /* ROCHE_REAL: length of the dose table along time */
+  int32_t lanes_per_patient; /* 0 = library chooses; 1 or 4 forces a variant (tuning / tests) */
+  int32_t need_theta_grad;   /* backward: also accumulate grad_theta */
+
+  const float* t;          /* [T] output grid == step grid (model.py:1072); strictly increasing */
+  const float* y0;         /* [B][D] */
+  const float* dosage;     /* ROCHE/NEURAL: [B] (set_action, model.py:498); ROCHE_REAL: [Ta][B] */
+  const float* dose_times; /* ROCHE/NEURAL: [B][K] fp32 times (model.py:502-507) */
+  const float* theta;      /* ROCHE: [HODE_N_THETA]; ROCHE_REAL: {k_immunity, kel, kel2} */
+  const float* w1;         /* ROCHE: ml_net.0.weight [D-4][D]; NEURAL: [10D][D+1]; REAL: packed (see hode_real.h) */
+  const float* b1;         /* ROCHE: ml_net.0.bias [D-4];      NEURAL: [10D] */
+  const float* w2;         /* NEURAL: [D][10D] */
+  const float* b2;         /* NEURAL: [D] */
+  float* h;                /* forward out / backward in: [T][B][D], h[0] = y0 */
+  int32_t* status;         /* device status word (may be NULL for fixed-grid calls) */
+
+  /* backward */
+  const float* grad_h;     /* [T][B][D] cotangent of h */
+  float* grad_y0;          /* out [B][D] */
+  float* grad_w1;          /* acc, shape of w1 */
+  float* grad_b1;          /* acc */
+  float* grad_w2;          /* acc */
+  float* grad_b2;          /* acc */
+  float* grad_theta;       /* acc [HODE_N_THETA] */
+
+  /* adaptive (dopri5) */
+  double rtol, atol;       /* reference passes 1e-7 / 1e-8 (model.py:1079-1080) */
+  int32_t max_steps;       /* tape capacity in accepted steps */
+  int32_t reserved0;
+  int32_t* host_n_accepted; /* HOST out (dopri5_fwd): accepted steps written to the tape */
+  int32_t* host_n_rejected; /* HOST out (dopri5_fwd) */
+
+  void* workspace;         /* device scratch, >= hode_workspace_bytes(desc, which) */
+  size_t workspace_bytes;
+} hode_solve_desc;
+
+/* LSTM encoder (reference EncoderLSTM.forward model.py:408-428, EncoderLSTMReal.forward :210-242) */
+typedef struct hode_lstm_desc {
+  uint32_t struct_size;
+  int32_t seq_len;     /* T */
+  int32_t batch;       /* B */
+  int32_t input_dim;   /* I = obs + action (+ statics + 1) */
+  int32_t hidden_dim;  /* H */
+  int32_t reverse;     /* 1: walk t = T-1 .. 0 (EncoderLSTM, model.py:420); 0: forward (EncoderLSTMReal) */
+  int32_t masked;      /* 1: input = x*mask (model.py:421) */
+  int32_t reserved0;
+  const float* x;      /* [T][B][I] */
+  const float* mask;   /* [T][B][I] or NULL */
+  const float* w_ih;   /* [4H][I]  gate order i,f,g,o (nn.LSTM) */
+  const float* w_hh;   /* [4H][H] */
+  const float* b_ih;   /* [4H] */
+  const float* b_hh;   /* [4H] */
+  float* h_out;        /* [B][H] final hidden state */
+  float* c_out;        /* [B][H] final cell state */
+  /* backward */
+  const float* grad_h_out; /* [B][H] */
+  float* grad_w_ih;    /* acc */
+  float* grad_w_hh;    /* acc */
+  float* grad_b_ih;    /* acc */
+  float* grad_b_hh;    /* acc */
+  void* workspace;     /* forward writes the gate/cell tape here when non-NULL; backward reads it */
+  size_t workspace_bytes;
+} hode_lstm_desc;
+
+#define HODE_WS_RK_FWD 0
+#define HODE_WS_RK_BWD 1
+#define HODE_WS_DOPRI5_FWD 2
+#define HODE_WS_DOPRI5_BWD 3
+
+int hode_version(void);
+const char* hode_last_error_string(void);
+
+/* bytes of device scratch the given entry point needs for this descriptor (0 if none) */
+size_t hode_workspace_bytes(const hode_solve_desc* desc, int which);
+size_t hode_lstm_workspace_bytes(const hode_lstm_desc* desc);
+
+/* fixed-grid solve: h[0] = y0, h[n+1] = h[n] + step(h[n]); one launch runs the whole time loop */
+int hode_rk_fwd(const hode_solve_desc* desc, void* hip_stream);
+/* discrete adjoint of hode_rk_fwd: reverse sweep that recomputes the stages of every step from h[n] */
+int hode_rk_bwd(const hode_solve_desc* desc, void* hip_stream);
+
+/* adaptive Dormand-Prince 5(4), torchdiffeq 0.2.2 semantics (batch-global controller, dense output).
+ * Synchronises the stream once per chunk of attempts to read the controller record. */
+int hode_dopri5_fwd(const hode_solve_desc* desc, void* hip_stream);
+int hode_dopri5_bwd(const hode_solve_desc* desc, void* hip_stream);
+
+int hode_lstm_fwd(const hode_lstm_desc* desc, void* hip_stream);
+int hode_lstm_bwd(const hode_lstm_desc* desc, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HODE_H_ */
