@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- patient-trajectories/sec (fwd + discrete adjoint) of the hybrid-ODE solver path on MI355X.
+
+Workload (BASELINE.json configs[1]): dim=12 synthetic, 10 000 patients PER GPU, T=100 grid points (dt=0.125),
+3/8-rule RK4, fused rhs+step HIP kernels.  One "step" = one forward solve + one discrete-adjoint solve over the
+rank's batch (+ one RCCL all-reduce of the parameter-gradient bucket when N>1).  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-graph]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
+
+import torch  # noqa: E402
+
+N_PER_GPU, T, D = 10000, 100, 12
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup quota (the GPU box gives a
+    16-core share of a much larger host; sizing thread pools by os.cpu_count() there oversubscribes badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, int(os.environ.get("HODE_CPU_THREADS", "16"))))
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def build_plan(dev, rank, lanes=0, need_theta=True):
+    from hode import synth
+    from hode.plan import RocheRKPlan
+    from hode.solver import pack_theta
+    inp = synth.solver_inputs(N_PER_GPU, T, D, seed=synth.SEED + rank)
+    w, b = synth.default_ml_weights(D)
+    theta = torch.tensor((2.0, 2.0) + (1.0,) * 11 + (0.0,) * 3)  # RochConfig defaults (sim_config.py:4-18)
+    chan = inp["actions"][..., 0]
+    dosage = chan.max(dim=0)[0]
+    times = (torch.nonzero((chan != 0).t())[:, 1].reshape(N_PER_GPU, -1) * synth.STEP).float()
+    plan = RocheRKPlan(inp["z0"].to(dev), theta.to(dev), w.to(dev), b.to(dev), inp["t"].to(dev), dosage.to(dev),
+                       times.to(dev), method="rk4", lanes_per_patient=lanes, need_theta_grad=need_theta)
+    gen = torch.Generator().manual_seed(99 + rank)
+    plan.grad_h.copy_(torch.randn(T, N_PER_GPU, D, generator=gen))  # synthetic cotangent (what the readout+loss would send)
+    return plan, inp, (w, b)
+
+
+def cpu_baseline(inp, wb, n_sample=2000, reps=3):
+    """The CPU oracle (op-for-op PyTorch eager restatement of the reference path, autograd backward) on a bounded
+    sample of the same workload: first `n_sample` patients, all host threads."""
+    from oracle.rhs import RocheRHS
+    from oracle.solvers import odeint
+    from hode import synth
+    torch.set_num_threads(host_cores())
+    f = RocheRHS(D, synth.STEP)
+    with torch.no_grad():
+        f.ml_net[0].weight.copy_(wb[0])
+        f.ml_net[0].bias.copy_(wb[1])
+    a = inp["actions"][:, :n_sample]
+    z0 = inp["z0"][:n_sample]
+    cot = torch.randn(T, n_sample, D, generator=torch.Generator().manual_seed(99))
+    times = []
+    dt = 0.0
+    for i in range(reps + 1):
+        if i == 1 and dt > 15.0:  # bounded: keep the whole CPU leg to tens of seconds
+            reps = 1
+        if i > reps:
+            break
+        t0 = time.perf_counter()
+        f.set_action(a)
+        y0 = z0.clone().requires_grad_(True)
+        f.zero_grad()
+        h = odeint(f, y0, inp["t"], method="rk4")
+        (h * cot).sum().backward()
+        dt = time.perf_counter() - t0
+        log("cpu_baseline rep %d: %.2f s (%d threads)" % (i, dt, torch.get_num_threads()))
+        if i > 0:
+            times.append(dt)
+    med = statistics.median(times)
+    return {"value": n_sample / med, "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "first %d of %d patients, T=%d, D=%d, rk4, fwd+autograd bwd, 1 warm-up + %d reps (median %.3f s)"
+                      % (n_sample, N_PER_GPU, T, D, reps, med)}
+
+
+def kernel_times(plan, iters=20):
+    """Average duration of the forward and backward launches, HIP events on the launch stream (torch's current)."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
+    for i in range(iters):
+        ev[i][0].record()
+        plan.forward()
+        ev[i][1].record()
+        plan.backward()
+        ev[i][2].record()
+    torch.cuda.synchronize()
+    fwd = statistics.mean(e[0].elapsed_time(e[1]) for e in ev) * 1e-3
+    bwd = statistics.mean(e[1].elapsed_time(e[2]) for e in ev) * 1e-3
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--lanes", type=int, default=0, help="force lanes per patient (1|4), 0 = library default")
+    ap.add_argument("--no-theta-grad", action="store_true", help="skip the 13 expert-constant gradients")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no HIP device visible (the solver path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+
+    plan, inp, wb = build_plan(dev, rank, lanes=args.lanes, need_theta=not args.no_theta_grad)
+    use_graph = not args.no_graph
+    log("rank %d: plan built (B=%d, T=%d, D=%d)" % (rank, N_PER_GPU, T, D))
+    if use_graph:
+        plan.capture()
+        log("rank %d: graph captured" % rank)
+
+    def step():
+        if use_graph:
+            plan.replay()
+        else:
+            plan.step()
+        if dist is not None:
+            dist.all_reduce(plan.grad_flat, op=dist.ReduceOp.AVG)  # data-parallel gradient exchange over xGMI
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    log("rank %d: %d steps in %.4f s" % (rank, args.steps, elapsed))
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    out = None
+    if rank == 0:
+        fwd_s, bwd_s = kernel_times(plan)
+        ms = elapsed / args.steps * 1e3
+        total = N_PER_GPU * world
+        ach = plan.bwd_bytes / bwd_s / 1e9
+        out = {
+            "metric": "patient-trajectories/sec (fwd+adjoint) at dim=12, T=100",
+            "value": total * args.steps / elapsed,
+            "unit": "trajectories/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "dim12 synthetic, %d patients/GPU, T=%d, dt=0.125, rk4(3/8), fused rhs+step kernel "
+                                   "+ discrete-adjoint kernel" % (N_PER_GPU, T),
+                       "patients_total": total, "launch": "hipGraph" if use_graph else "eager",
+                       "lanes_per_patient": args.lanes or "auto", "theta_grad": not args.no_theta_grad,
+                       "parallelism": "dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "rk_bwd_kernel<12,...> (+fold_partials)", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": plan.bwd_bytes, "avg_launch_us": bwd_s * 1e6,
+                         "fwd": {"bytes_per_launch": plan.fwd_bytes, "avg_launch_us": fwd_s * 1e6,
+                                 "achieved": plan.fwd_bytes / fwd_s / 1e9},
+                         "step_frac": (plan.fwd_bytes + plan.bwd_bytes) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(inp, wb)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""Data parallelism over the patient axis: one process per GPU, contiguous batch shards, one flat-bucket all-reduce.
+
+Patients are independent in the ODE, the encoder, the likelihood and the KL; the only exchange of the path is the
+parameter gradient.  ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI within a node);
+"gloo" is used by the CPU tests.  The bucket is a few hundred KB at most (160 528 floats at dim12), i.e. latency
+bound: a single collective per step, no per-layer bucketing.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank0_print(*args, **kw):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+        print(*args, **kw)
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous split of n patients; the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(data: dict, rank: int = None, world: int = None) -> dict:
+    """Slice dim 1 (patients) of every (T, B, .) tensor of a reference-style data dict for this rank."""
+    if rank is None:
+        rank, world = dist.get_rank(), dist.get_world_size()
+    n = next(iter(data.values())).shape[1]
+    lo, hi = shard_bounds(n, rank, world)
+    return {k: v[:, lo:hi] for k, v in data.items()}
+
+
+class GradBucket:
+    """Flat fp32 view over the gradients of a parameter list; ``all_reduce_mean`` averages them across ranks.
+
+    Losses are normalised per local batch (reference model.py:1179,1188), so with equal shards the mean of the
+    per-rank gradients equals the global-batch gradient; with unequal shards pass ``weight = local_B / global_B * world``.
+    """
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        first = self.params[0]
+        self.flat = torch.zeros(self.numel, device=first.device, dtype=torch.float32)
+
+    def _gather(self, weight=1.0):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        if weight != 1.0:
+            self.flat.mul_(weight)
+
+    def _scatter(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+    def all_reduce_mean(self, weight=1.0):
+        self._gather(weight)
+        if is_distributed():
+            if dist.get_backend() == "gloo":  # gloo has no AVG
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.flat.div_(dist.get_world_size())
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+        self._scatter()
+        return self.flat

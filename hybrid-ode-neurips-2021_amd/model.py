@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's ``model.py`` call surface for the hybrid-ODE hot path.
+
+Same class names, constructor signatures, attribute names, parameter creation order and ``state_dict`` keys as the
+reference (so ``run_simulation.py`` / ``training_utils.py`` style drivers and reference checkpoints drop in), but the
+latent ODE is integrated by the gfx950 kernels of ``libhode.so`` (``hode.odeint``) instead of ``torchdiffeq``:
+
+    reference                                  here
+    RocheODE            model.py:446-555       RocheODE            (+ ``hode_solve``: kernel dispatch)
+    RocheExpertDecoder  model.py:1030-1121     RocheExpertDecoder  (forward = set_action -> hode.odeint -> readout)
+    EncoderLSTM         model.py:383-440       EncoderLSTM
+    GaussianReparam / ExponentialPrior / StandardNormalPrior  model.py:18-45
+    VariationalInference model.py:1124-1214    VariationalInference
+
+Out of scope: flow encoders, baselines, real-data variants (added with config 5).
+"""
+
+from __future__ import annotations
+
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+import hode
+import sim_config
+from global_config import DTYPE, get_device
+
+_LOG_SQRT_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+class GaussianReparam:
+    """Diagonal-Gaussian posterior helpers (reference model.py:18-31)."""
+
+    @staticmethod
+    def reparameterize(mu, log_var):
+        sigma = torch.exp(0.5 * log_var)
+        return torch.randn_like(sigma) * sigma + mu
+
+    @staticmethod
+    def log_density(mu, log_var, z):
+        sigma = torch.exp(0.5 * log_var)
+        lp = -((z - mu) ** 2) / (2 * sigma ** 2) - sigma.log() - _LOG_SQRT_2PI
+        return lp.sum(dim=-1)
+
+
+class StandardNormalPrior:
+    @staticmethod
+    def log_density(z):
+        return (-0.5 * z ** 2 - _LOG_SQRT_2PI).sum(dim=-1)
+
+
+class ExponentialPrior:
+    """Exponential(rate 100) prior on the initial latents (reference model.py:41-45)."""
+
+    rate = 100.0
+
+    @staticmethod
+    def log_density(z):
+        return (math.log(ExponentialPrior.rate) - ExponentialPrior.rate * z).sum(dim=-1)
+
+
+class EncoderLSTM(nn.Module, GaussianReparam):
+    """Masked, reverse-time single-layer LSTM over the observation window -> (mu, log_var) of z0 (model.py:383-440)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, normalize=True, device=None):
+        super().__init__()
+        self.device = get_device() if device is None else device
+        self.hidden_dim = hidden_dim
+        self.normalize = normalize
+        self.model_name = "LSTMEncoder"
+        # creation order lstm -> lin -> log_var fixes both the seeded init and the state_dict key order
+        self.lstm = nn.LSTM(input_dim, hidden_dim).to(self.device)
+        self.lin = nn.Linear(hidden_dim, output_dim).to(self.device)
+        self.log_var = nn.Linear(hidden_dim, output_dim).to(self.device)
+
+    def final_hidden(self, x, a, mask):
+        """h after walking t = T-1 .. 0 on cat(x,a)*cat(mask,1).  One fused sequence call on the time-flipped,
+        pre-masked input replaces the reference's T single-step ``nn.LSTM`` calls (same arithmetic)."""
+        if x.dim() == 3 and x.shape[1] == 1:
+            raise RuntimeError("EncoderLSTM: batch size 1 is not supported (the reference's x.squeeze() drops the batch axis)")
+        seq = torch.cat([x * mask, a], dim=-1).flip(0)
+        _, (h, _) = self.lstm(seq)
+        return h[0]
+
+    def forward(self, x, a, mask):
+        h = self.final_hidden(x, a, mask)
+        mu, log_var = self.lin(h), self.log_var(h)
+        if self.normalize:
+            mu = torch.exp(mu) / 10
+            log_var = log_var - 5.0
+        return mu, log_var
+
+
+_THETA_FIELDS = sim_config.RochConfig._fields  # == parameter creation order of the reference (model.py:468-482)
+
+
+class RocheODE(nn.Module):
+    """Expert PK/PD block + ``tanh(W y + b)`` learned block; ``forward(t, y)`` is the rhs (model.py:446-555)."""
+
+    def __init__(self, latent_dim, action_dim, t_max, step_size, ablate=False, device=None, dtype=DTYPE):
+        super().__init__()
+        assert action_dim == 1
+        self.action_dim = action_dim
+        self.latent_dim = int(latent_dim)
+        self.expert_dim = 4
+        self.ml_dim = self.latent_dim - self.expert_dim
+        self.expanded = self.ml_dim > 0
+        self.ablate = ablate
+        self.device = get_device() if device is None else device
+        self.t_max = t_max
+        self.step_size = step_size
+        cfg = sim_config.RochConfig()
+        for name in _THETA_FIELDS:
+            setattr(self, name, nn.Parameter(torch.tensor(getattr(cfg, name), device=self.device, dtype=dtype)))
+        if self.ablate:
+            self.theta_1 = nn.Parameter(torch.tensor(1, device=self.device, dtype=dtype))
+            self.theta_2 = nn.Parameter(torch.tensor(2, device=self.device, dtype=dtype))
+        if self.expanded:
+            self.ml_net = nn.Sequential(nn.Linear(self.latent_dim, self.ml_dim), nn.Tanh()).to(self.device)
+        else:
+            self.ml_net = nn.Identity().to(self.device)
+        self.times = None
+        self.dosage = None
+        # tuning knobs of the kernel dispatch (not part of the reference surface)
+        self.lanes_per_patient = 0
+        self.check_finite = False
+
+    # -- dose schedule -------------------------------------------------------------------------------------
+    def set_action(self, action):
+        """dosage (B,) = max over time; times (B, K) = non-zero grid indices * step_size.  Vectorised: the
+        reference's per-patient Python loop (model.py:500-507) costs 0.19 s at 10k patients."""
+        chan = action[..., 0]
+        self.dosage = torch.max(chan, dim=0)[0]
+        hit = (chan != 0).t()
+        counts = hit.sum(dim=1)
+        k = int(counts[0]) if counts.numel() else 0
+        if counts.numel() and not bool((counts == k).all()):
+            raise RuntimeError("stack expects each tensor to be equal size (patients have different dose counts)")
+        self.times = torch.nonzero(hit)[:, 1].reshape(hit.shape[0], k) * self.step_size
+
+    def dose_at_time(self, t):
+        on = t >= self.times
+        return self.dosage * torch.sum(torch.exp(self.kel * (self.times - t) * on) * on, dim=-1)
+
+    # -- rhs as a torch function (API parity; the solver never calls this) ----------------------------------
+    def forward(self, t, y):
+        dis, ir, imm, dose2 = y[:, 0], y[:, 1], y[:, 2], y[:, 3]
+        if self.ablate:
+            cols = [ir, -1.0 * dis * self.theta_1, dose2, -1.0 * imm * self.theta_2]
+        else:
+            dose = self.dose_at_time(t)
+            irp = ir ** self.HillPatho
+            cols = [
+                dis * self.k_disprog - dis * imm ** self.HillCure * self.k_discure_immunity - dis * ir * self.k_discure_immunereact,
+                dis * self.k_immune_disease - ir * self.k_immune_off + dis * ir * self.k_immune_feedback
+                + (irp * self.emax_patho) / (self.ec50_patho ** self.HillPatho + irp) - dose2 * ir * self.k_dexa,
+                ir * self.k_immunity,
+                self.kel * dose - self.kel * dose2,
+            ]
+        out = torch.stack(cols, dim=-1)
+        return torch.cat([out, self.ml_net(y)], dim=-1) if self.expanded else out
+
+    # -- kernel dispatch (what hode.odeint calls) -----------------------------------------------------------
+    def theta_vector(self):
+        names = list(_THETA_FIELDS) + (["theta_1", "theta_2"] if self.ablate else [])
+        return hode.solver.pack_theta([getattr(self, n) for n in names], self.device)
+
+    def hode_solve(self, y0, t, rtol, atol, method, options):
+        if self.times is None:
+            raise RuntimeError("RocheODE: call set_action(a) before integrating")
+        w = self.ml_net[0].weight if self.expanded else None
+        b = self.ml_net[0].bias if self.expanded else None
+        if method == "dopri5":
+            from hode import adaptive
+            return adaptive.roche_dopri5(y0, self.theta_vector(), w, b, t, self.dosage, self.times, rtol=rtol, atol=atol,
+                                         ablate=self.ablate)
+        step_size = options.pop("step_size", None)
+        if step_size is not None:
+            raise hode.HodeError("hode: options['step_size'] (sub-stepping between output times) is not supported yet")
+        return hode.roche_solve(y0, self.theta_vector(), w, b, t, self.dosage, self.times, method=method, ablate=self.ablate,
+                                perturb=bool(options.pop("perturb", False)), lanes_per_patient=self.lanes_per_patient,
+                                check_finite=self.check_finite)
+
+
+class RocheExpertDecoder(nn.Module):
+    """z0 -> latent trajectory h (T,B,D) on the observation grid -> linear readout x_hat (model.py:1030-1121)."""
+
+    def __init__(self, obs_dim, latent_dim, action_dim, t_max, step_size, roche=True, ablate=False, method="dopri5",
+                 ode_step_size=None, device=None, dtype=DTYPE):
+        super().__init__()
+        self.time_dim = int(t_max / step_size)
+        self.obs_dim, self.latent_dim, self.action_dim = obs_dim, latent_dim, action_dim
+        self.t_max, self.step_size = t_max, step_size
+        self.roche, self.ablate = roche, ablate
+        self.model_name = ("ExpertDecoder" if latent_dim == 4 else "HybridDecoder") if roche else "NeuralODEDecoder"
+        if ablate:
+            self.model_name += "Ablate"
+            print("Running ablation study")
+        self.device = get_device() if device is None else device
+        self.t = torch.arange(0, t_max + step_size, step_size, device=self.device, dtype=dtype)
+        self.options = {"method": method, "rtol": 1e-7, "atol": 1e-8}
+        # readout first, then the ode: same parameter creation order as the reference (seeded-init parity)
+        self.output_function = nn.Sequential(nn.Linear(latent_dim, obs_dim, bias=True)).to(self.device)
+        if roche:
+            self.ode = RocheODE(latent_dim, action_dim, t_max, step_size, ablate=ablate, device=self.device)
+        else:
+            raise hode.HodeError("RocheExpertDecoder(roche=False): the NeuralODE rhs kernel is not built yet")
+        self._odeint = hode.odeint  # tests swap in the CPU oracle here; the product path never does
+
+    def forward(self, init, a):
+        self.ode.set_action(a)
+        h = self._odeint(self.ode, init, self.t, rtol=self.options["rtol"], atol=self.options["atol"],
+                         method=self.options["method"])
+        return self.output_function(h), h
+
+
+class VariationalInference:
+    """Negative ELBO: masked SSE likelihood + KL (analytic vs N(0,1), or Monte-Carlo vs a given prior) (model.py:1124-1214)."""
+
+    epsilon = torch.finfo(DTYPE).eps
+
+    def __init__(self, encoder, decoder, elbo=True, prior_log_pdf=None, mc_size=100):
+        self.encoder, self.decoder = encoder, decoder
+        self.prior_log_pdf = prior_log_pdf
+        self.mc_size = mc_size
+        self.elbo = elbo
+        self.model_name = "VI_{}_{}.pkl".format(encoder.model_name, decoder.model_name)
+
+    def save(self, path, itr, best_loss):
+        path = path + self.model_name
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"itr": itr, "encoder_state_dict": self.encoder.state_dict(),
+                    "decoder_state_dict": self.decoder.state_dict(), "best_loss": best_loss}, path)
+
+    def parameters(self):
+        return list(self.encoder.parameters()) + list(self.decoder.parameters())
+
+    def loss(self, data):
+        x, a, mask = data["measurements"], data["actions"], data["masks"]
+        self.x, self.a, self.mask = x, a, mask
+        mu, log_var = self.encoder(x, a, mask)
+        self.mu, self.log_var = mu, log_var
+        z = self.encoder.reparameterize(mu, log_var) if self.elbo else mu
+        self.z = z
+        x_hat, h_hat = self.decoder(z, a)
+        self.x_hat, self.h_hat = x_hat, h_hat
+        lik = torch.sum((x - x_hat) ** 2 * mask) / x.shape[1]
+        if not self.elbo:
+            return lik
+        if self.prior_log_pdf is None:
+            kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+        else:
+            kld = torch.mean(self.mc_kl(mu, log_var, self.mc_size), dim=0)
+        return lik + kld
+
+    def mc_kl(self, mu, log_var, sample_size):
+        """E_q[log q - log p] from `sample_size` draws, non-positive draws clamped to eps.  All draws in one batched
+        tensor (sample axis first) instead of the reference's Python loop; same RNG stream order."""
+        sigma = torch.exp(0.5 * log_var)
+        eps = torch.randn((sample_size,) + tuple(sigma.shape), device=sigma.device, dtype=sigma.dtype)
+        z = eps * sigma + mu
+        z = torch.where(z <= 0.0, torch.full_like(z, self.epsilon), z)
+        log_q = self.encoder.log_density(mu, log_var, z)
+        return torch.mean(log_q - self.prior_log_pdf(z), dim=0)
