@@ -12,7 +12,7 @@ CSRC = os.path.join(ROOT, "hybrid-ode-neurips-2021_amd", "csrc")
 OUT = os.path.join(ROOT, "hybrid-ode-neurips-2021_amd", "hode", "libhode.so")
 OBJ = os.path.join(CSRC, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-variable",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable",
          "-Wno-unused-but-set-variable"]
 RK_DIMS = (4, 6, 8, 12, 20)
 

@@ -23,22 +23,18 @@ static int hip_fail(hipError_t e, const char* what) {
   return (int)e;
 }
 
-// out[j] += sum over waves of partials[w][j], in wave order (deterministic)
-__global__ void fold_partials_kernel(const float* __restrict__ partials, int n_waves, int P, int n_w, int n_b,
-                                     float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gth,
-                                     int need_th) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= P) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int w = 0;
-  for (; w + 3 < n_waves; w += 4) {
-    s0 += partials[(size_t)w * P + j];
-    s1 += partials[(size_t)(w + 1) * P + j];
-    s2 += partials[(size_t)(w + 2) * P + j];
-    s3 += partials[(size_t)(w + 3) * P + j];
-  }
-  for (; w < n_waves; ++w) s0 += partials[(size_t)w * P + j];
-  const float s = (s0 + s1) + (s2 + s3);
+// out[j] += sum over waves of partials[w][j].  One wave per output element: lane l adds rows l, l+64, ... in order,
+// then a fixed-shape butterfly folds the 64 lane sums -- the summation tree depends only on (n_waves), so the
+// result is bit-reproducible run to run (no float atomics).
+__global__ __launch_bounds__(64) void fold_partials_kernel(const float* __restrict__ partials, int n_waves, int P,
+                                                           int n_w, int n_b, float* __restrict__ gw,
+                                                           float* __restrict__ gb, float* __restrict__ gth, int need_th) {
+  const int j = blockIdx.x;
+  const int lane = threadIdx.x;
+  float s = 0.f;
+  for (int w = lane; w < n_waves; w += 64) s += partials[(size_t)w * P + j];
+  s = wave_sum(s);
+  if (lane != 0) return;
   if (j < n_w) {
     if (gw) gw[j] += s;
   } else if (j < n_w + n_b) {
@@ -47,7 +43,6 @@ __global__ void fold_partials_kernel(const float* __restrict__ partials, int n_w
     gth[j - n_w - n_b] += s;
   }
 }
-
 
 }  // namespace hode
 
@@ -155,7 +150,7 @@ extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
   const int M = d->latent_dim - 4;
   const int P = n_partials(d);
   const int nw = n_waves_for(d->batch, choose_lpp(d));
-  hipLaunchKernelGGL(hode::fold_partials_kernel, dim3((P + 63) / 64), dim3(64), 0, s, (const float*)d->workspace, nw, P,
+  hipLaunchKernelGGL(hode::fold_partials_kernel, dim3(P), dim3(64), 0, s, (const float*)d->workspace, nw, P,
                      M * d->latent_dim, M, d->grad_w1, d->grad_b1, d->grad_theta, d->need_theta_grad);
   return hode::hip_fail(hipGetLastError(), "fold_partials launch");
 }

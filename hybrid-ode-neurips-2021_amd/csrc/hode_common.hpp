@@ -13,22 +13,29 @@ constexpr int kWave = 64;
 // transcendental helpers.  Accuracy targets are stated per function and checked in tests/test_hip_math.py.
 // ---------------------------------------------------------------------------------------------------------
 
-// exp(x) for the dose decay: |x| is bounded by kel * t_max (tens), 2-ulp v_exp_f32 after a split multiply so
-// that the argument reduction does not lose bits for |x| up to ~80.
+// exp(x), x <= 0 in practice (dose decay kel*(tau - t)): hardware exp2 of the rounded product x*log2(e), corrected
+// by the product's rounding residual (exact via fma).  <= 2 ulp for |x| < 80; 5 instructions.
 HODE_DEV float exp_f32(float x) {
-  // x*log2(e) in two pieces (hi product + fma correction), then hardware exp2
   const float l2e = 1.4426950408889634f;
-  float hi = x * l2e;
-  float lo = __builtin_fmaf(x, l2e, -hi) + x * 1.925963033500011e-08f;  // log2e - (float)log2e
-  float r = __builtin_rintf(hi);
-  float f = (hi - r) + lo;
-  float e = __builtin_amdgcn_exp2f(f);
-  return __builtin_amdgcn_ldexpf(e, (int)r);  // ldexp handles over/underflow to inf / 0
+  const float t = x * l2e;
+  const float lo = __builtin_fmaf(x, l2e, -t);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
 }
 
-// tanh(x): odd polynomial x + x^3 P(x^2) for |x| < 0.625 (own minimax fit, 1.3 ulp), 1 - 2/(exp(2|x|)+1) above
-// (<= 3 ulp, absolute error <= 1.2e-7).  NaN propagates, +-inf -> +-1.
+// natural log through the hardware log2 (only used by the Hill-exponent gradients)
+HODE_DEV float log_f32(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1): v_mul, v_exp, v_add, v_rcp, v_fma.  ABSOLUTE error <= 1.5e-7 over the whole
+// line (checked against fp64 in tests/test_hip_math.py); the relative error grows for |x| << 1, which does not
+// matter here because tanh feeds an additive rate dy/dt.  NaN propagates, +-inf -> +-1.
 HODE_DEV float tanh_f32(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);  // exp(2x)
+  return __builtin_fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
+}
+
+// tanh with ~1.3 ulp RELATIVE accuracy (odd polynomial below 0.625, exp form above); kept for the encoder gates
+HODE_DEV float tanh_precise_f32(float x) {
   float ax = __builtin_fabsf(x);
   float u = x * x;
   float p = -0.005508354399353266f;
@@ -37,7 +44,7 @@ HODE_DEV float tanh_f32(float x) {
   p = __builtin_fmaf(p, u, 0.13330785930156708f);
   p = __builtin_fmaf(p, u, -0.3333325684070587f);
   float small = __builtin_fmaf(ax * u, p, ax);
-  float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);  // exp(2|x|)
+  float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
   float big = __builtin_fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
   float r = ax < 0.625f ? small : big;
   return __builtin_copysignf(r, x);

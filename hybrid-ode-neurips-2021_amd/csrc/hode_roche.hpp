@@ -47,6 +47,25 @@ struct MlSlice {
   }
 };
 
+// per-lane COLUMN slice of W for the transposed product a = W^T u of the VJP: columns [q*DC, (q+1)*DC).
+// Only the quad layout needs it (with LPP = 1 the lane owns all of W already).
+template <int D, int LPP>
+struct MlColSlice {
+  static constexpr int M = D - 4;
+  static constexpr int DC = (LPP > 1 && M > 0) ? D / LPP : 1;
+  static constexpr int MM = (LPP > 1 && M > 0) ? M : 1;
+  float wt[MM][DC];
+  HODE_DEV void load(const float* __restrict__ W, int q) {
+    if constexpr (LPP > 1 && M > 0) {
+      static_assert(D % LPP == 0, "quad layout needs D % 4 == 0");
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) wt[j][c] = W[j * D + q * DC + c];
+    }
+  }
+};
+
 // select v[q*MR + r] for a run-time quad position q out of compile-time indexed registers
 template <int LPP, int MR, int N>
 HODE_DEV float pick_own(const float (&v)[N], int base, int r, int q) {
@@ -80,29 +99,36 @@ HODE_DEV void gather_rows(const float (&own)[MlSlice<D, LPP>::MR], float (&k)[D]
 }
 
 // dose schedule of one patient: Dose(t) = dosage * sum_k 1[t >= tau_k] exp(kel (tau_k - t))   (model.py:509-513)
+struct DoseVal {
+  float v;   // Dose(t)
+  float dk;  // d Dose / d kel
+};
+template <bool K1>
 struct DoseSched {
   float dosage;
-  float tau0;               // K == 1 fast path
-  const float* taus;        // [K] for this patient (global memory), used when K > 1
+  float tau0;         // K == 1 (one dose per patient: every shipped synthetic configuration)
+  const float* taus;  // [K] for this patient in global memory, walked when K != 1
   int K;
-  HODE_DEV float at(float t, float kel) const {
-    if (K == 1) return (t >= tau0) ? dosage * exp_f32(kel * (tau0 - t)) : 0.0f;
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) {
-      float tau = taus[k];
-      s += (t >= tau) ? exp_f32(kel * (tau - t)) : 0.0f;
+  HODE_DEV DoseVal at(float t, float kel) const {
+    DoseVal r;
+    if constexpr (K1) {
+      const float d = tau0 - t;
+      const float v = (t >= tau0) ? dosage * exp_f32(kel * d) : 0.0f;
+      r.v = v;
+      r.dk = d * v;
+    } else {
+      float s = 0.f, sk = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float tau = taus[k];
+        const float d = tau - t;
+        const float e = (t >= tau) ? exp_f32(kel * d) : 0.0f;
+        s += e;
+        sk = __builtin_fmaf(d, e, sk);
+      }
+      r.v = dosage * s;
+      r.dk = dosage * sk;
     }
-    return dosage * s;
-  }
-  // d Dose / d kel
-  HODE_DEV float dkel(float t, float kel) const {
-    if (K == 1) return (t >= tau0) ? dosage * (tau0 - t) * exp_f32(kel * (tau0 - t)) : 0.0f;
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) {
-      float tau = taus[k];
-      s += (t >= tau) ? (tau - t) * exp_f32(kel * (tau - t)) : 0.0f;
-    }
-    return dosage * s;
+    return r;
   }
 };
 
@@ -119,7 +145,7 @@ HODE_DEV float dpow_dx(float x, float p) {
   else return p == 0.0f ? 0.0f : p * powf(x, p - 1.0f);
 }
 // d/dp x**p = x**p log x   (torch pow_backward_exponent: zero where x == 0 and p >= 0)
-HODE_DEV float dpow_dp(float x, float p, float xp) { return (x == 0.0f && p >= 0.0f) ? 0.0f : xp * logf(x); }
+HODE_DEV float dpow_dp(float x, float p, float xp) { return (x == 0.0f && p >= 0.0f) ? 0.0f : xp * log_f32(x); }
 
 // k = f(t, Y).  `own` receives this lane's tanh outputs (needed again by the VJP).
 template <int D, int LPP, bool ABLATE, bool HILL2>
@@ -174,12 +200,15 @@ struct GradAcc {
 
 // Vector-Jacobian product of the rhs at (t, Y): a = (df/dY)^T g, and parameter-gradient accumulation.
 //   own_s : this lane's tanh outputs at Y (from roche_rhs), g : cotangent of k (full, all lanes), q : quad position.
+// Quad layout: u is all-gathered (M DPP moves), every lane forms D/4 entries of W^T u from its column slice
+// (M*D/4 fmas) and the entries are all-gathered again (D DPP moves) -- cheaper than a D-wide quad all-reduce.
 template <int D, int LPP, bool ABLATE, bool HILL2, bool NEED_TH>
-HODE_DEV void roche_vjp(const RocheTheta& th, const MlSlice<D, LPP>& ml, const DoseSched& ds, float t, float dose,
-                        const float (&Y)[D], const float (&own_s)[MlSlice<D, LPP>::MR], const float (&g)[D], int q,
-                        float (&a)[D], GradAcc<D, LPP>& acc) {
+HODE_DEV void roche_vjp(const RocheTheta& th, const MlSlice<D, LPP>& ml, const MlColSlice<D, LPP>& mc, float ln_ec50,
+                        DoseVal dose, const float (&Y)[D], const float (&own_s)[MlSlice<D, LPP>::MR],
+                        const float (&g)[D], int q, float (&a)[D], GradAcc<D, LPP>& acc) {
   constexpr int MR = MlSlice<D, LPP>::MR;
-  // ---- learned block: u_r = g_r (1 - s_r^2); a_i = sum_r W[r][i] u_r (summed over the patient's lanes)
+  constexpr int M = D - 4;
+  // ---- learned block: u_r = g_r (1 - s_r^2)
   if constexpr (D > 4) {
     float u[MR];
 #pragma unroll
@@ -187,17 +216,37 @@ HODE_DEV void roche_vjp(const RocheTheta& th, const MlSlice<D, LPP>& ml, const D
       const float gr = pick_own<LPP, MR, D>(g, 4, r, q);
       u[r] = gr * __builtin_fmaf(-own_s[r], own_s[r], 1.0f);
       acc.db[r] += u[r];
-    }
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      float p = 0.f;
+      for (int i = 0; i < D; ++i) acc.dw[r][i] = __builtin_fmaf(u[r], Y[i], acc.dw[r][i]);
+    }
+    if constexpr (LPP == 1) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        float p = 0.f;
+#pragma unroll
+        for (int r = 0; r < MR; ++r) p = __builtin_fmaf(ml.w[r][i], u[r], p);
+        a[i] = p;
+      }
+    } else {
+      constexpr int DC = MlColSlice<D, LPP>::DC;
+      float uf[M];
 #pragma unroll
       for (int r = 0; r < MR; ++r) {
-        p = __builtin_fmaf(ml.w[r][i], u[r], p);
-        acc.dw[r][i] = __builtin_fmaf(u[r], Y[i], acc.dw[r][i]);
+        uf[0 * MR + r] = quad_bcast<0>(u[r]);
+        uf[1 * MR + r] = quad_bcast<1>(u[r]);
+        uf[2 * MR + r] = quad_bcast<2>(u[r]);
+        uf[3 * MR + r] = quad_bcast<3>(u[r]);
       }
-      if constexpr (LPP == 4) p = quad_sum(p);
-      a[i] = p;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) p = __builtin_fmaf(mc.wt[j][c], uf[j], p);
+        a[0 * DC + c] = quad_bcast<0>(p);
+        a[1 * DC + c] = quad_bcast<1>(p);
+        a[2 * DC + c] = quad_bcast<2>(p);
+        a[3 * DC + c] = quad_bcast<3>(p);
+      }
     }
   } else {
 #pragma unroll
@@ -210,39 +259,39 @@ HODE_DEV void roche_vjp(const RocheTheta& th, const MlSlice<D, LPP>& ml, const D
     const float immp = pow_hill<HILL2>(imm, th.hc);
     const float irp = pow_hill<HILL2>(ir, th.hp);
     const float ecp = pow_hill<HILL2>(th.ec50, th.hp);
-    const float den = ecp + irp;
-    const float rden = div_f32(1.0f, den);
+    const float rden = __builtin_amdgcn_rcpf(ecp + irp);
     const float dirp = dpow_dx<HILL2>(ir, th.hp);
+    const float g0d = g0 * dis, g1d = g1 * dis, g1i = g1 * ir;
+    const float er2 = th.emax * rden * rden;  // emax / (E + P)^2
     a[0] += g0 * (th.kprog - immp * th.kci - ir * th.kcir) + g1 * (th.kid + ir * th.kfb);
-    a[1] += g0 * (-dis * th.kcir) +
-            g1 * (-th.koff + dis * th.kfb + th.emax * ecp * dirp * rden * rden - d2 * th.kdexa) + g2 * th.kim;
-    a[2] += g0 * (-dis * th.kci * dpow_dx<HILL2>(imm, th.hc));
-    a[3] += g1 * (-ir * th.kdexa) - g3 * th.kel;
+    a[1] += g1 * (dis * th.kfb - th.koff + er2 * ecp * dirp - d2 * th.kdexa) - g0d * th.kcir + g2 * th.kim;
+    a[2] -= g0d * th.kci * dpow_dx<HILL2>(imm, th.hc);
+    a[3] -= g1i * th.kdexa + g3 * th.kel;
     if constexpr (NEED_TH) {
-      const float frac = irp * rden;  // P/(E+P)
-      acc.dth[0] += g0 * (-dis * th.kci * dpow_dp(imm, th.hc, immp));
-      const float dP = dpow_dp(ir, th.hp, irp), dE = dpow_dp(th.ec50, th.hp, ecp);
-      acc.dth[1] += g1 * th.emax * (dP * ecp - irp * dE) * rden * rden;
-      acc.dth[2] += g1 * (-irp * th.emax * rden * rden * dpow_dx<HILL2>(th.ec50, th.hp));
-      acc.dth[3] += g1 * frac;
-      acc.dth[4] += g1 * (-d2 * ir);
-      acc.dth[5] += g0 * (-dis * ir);
-      acc.dth[6] += g0 * (-dis * immp);
-      acc.dth[7] += g0 * dis;
-      acc.dth[8] += g1 * dis;
-      acc.dth[9] += g1 * dis * ir;
-      acc.dth[10] += g1 * (-ir);
+      acc.dth[0] -= g0d * th.kci * dpow_dp(imm, th.hc, immp);
+      const float dP = dpow_dp(ir, th.hp, irp);
+      const float dE = (th.ec50 == 0.0f && th.hp >= 0.0f) ? 0.0f : ecp * ln_ec50;
+      acc.dth[1] += g1 * er2 * (dP * ecp - irp * dE);
+      acc.dth[2] -= g1 * er2 * irp * dpow_dx<HILL2>(th.ec50, th.hp);
+      acc.dth[3] += g1 * irp * rden;
+      acc.dth[4] -= g1i * d2;
+      acc.dth[5] -= g0d * ir;
+      acc.dth[6] -= g0d * immp;
+      acc.dth[7] += g0d;
+      acc.dth[8] += g1d;
+      acc.dth[9] += g1d * ir;
+      acc.dth[10] -= g1i;
       acc.dth[11] += g2 * ir;
-      acc.dth[12] += g3 * ((dose - d2) + th.kel * ds.dkel(t, th.kel));
+      acc.dth[12] += g3 * ((dose.v - d2) + th.kel * dose.dk);
     }
   } else {
-    a[0] += -th.th1 * g1;
+    a[0] -= th.th1 * g1;
     a[1] += g0;
-    a[2] += -th.th2 * g3;
+    a[2] -= th.th2 * g3;
     a[3] += g2;
     if constexpr (NEED_TH) {
-      acc.dth[13] += -dis * g1;
-      acc.dth[14] += -imm * g3;
+      acc.dth[13] -= dis * g1;
+      acc.dth[14] -= imm * g3;
     }
   }
 }
