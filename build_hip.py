@@ -15,12 +15,15 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-variable",
          "-Wno-unused-but-set-variable"]
 RK_DIMS = (4, 6, 8, 12, 20)
+DP_DIMS = (4, 6, 8, 12)
 
 
 def units():
     u = [("hode_api", os.path.join(CSRC, "hode_api.hip"), [])]
     for d in RK_DIMS:
         u.append(("hode_rk_d%d" % d, os.path.join(CSRC, "hode_rk_dim.hip"), ["-DHODE_DIM=%d" % d]))
+    for d in DP_DIMS:
+        u.append(("hode_dp_d%d" % d, os.path.join(CSRC, "hode_dopri5_dim.hip"), ["-DHODE_DIM=%d" % d]))
     for name in ("hode_dopri5", "hode_lstm"):
         src = os.path.join(CSRC, name + ".hip")
         if os.path.exists(src):
@@ -48,7 +51,7 @@ def compile_one(name, src, extra, force, dep_time):
     return name, time.time() - t0, r.stderr
 
 
-def build(jobs=6, force=False, verbose=True):
+def build(jobs=7, force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     dep = newest_dep()
     us = units()
@@ -73,7 +76,7 @@ def build(jobs=6, force=False, verbose=True):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("-j", type=int, default=6)
+    ap.add_argument("-j", type=int, default=7)
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
     build(a.j, a.force)

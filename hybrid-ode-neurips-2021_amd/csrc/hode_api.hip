@@ -17,7 +17,7 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-static int hip_fail(hipError_t e, const char* what) {
+int hip_fail(hipError_t e, const char* what) {
   if (e == hipSuccess) return 0;
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return (int)e;
@@ -44,13 +44,6 @@ __global__ __launch_bounds__(64) void fold_partials_kernel(const float* __restri
   }
 }
 
-}  // namespace hode
-
-namespace {
-
-using hode::RkArgs;
-using hode::RkLaunch;
-
 int n_waves_for(int B, int lpp) { return (int)(((long long)B * lpp + 63) / 64); }
 
 // LPP = 4 (a patient per DPP quad, 16 patients per wave) fills the chip at the 10k-patient shape; LPP = 1 has
@@ -67,8 +60,26 @@ int choose_lpp(const hode_solve_desc* d) {
 
 int n_partials(const hode_solve_desc* d) {
   const int M = d->latent_dim - 4;
-  return M * d->latent_dim + M + hode::kNTheta;
+  return M * d->latent_dim + M + kNTheta;
 }
+
+
+int launch_fold_partials(const float* partials, int n_waves, int P, int n_w, int n_b, float* gw, float* gb, float* gth,
+                         int need_th, hipStream_t s) {
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(P), dim3(64), 0, s, partials, n_waves, P, n_w, n_b, gw, gb, gth, need_th);
+  return hip_fail(hipGetLastError(), "fold_partials launch");
+}
+
+}  // namespace hode
+
+namespace {
+
+using hode::choose_lpp;
+using hode::n_partials;
+using hode::n_waves_for;
+
+using hode::RkArgs;
+using hode::RkLaunch;
 
 RkArgs make_args(const hode_solve_desc* d) {
   RkArgs a{};
@@ -122,6 +133,8 @@ int check_rk(const hode_solve_desc* d, bool bwd) {
 
 }  // namespace
 
+extern "C" size_t hode_dopri5_workspace_bytes(const hode_solve_desc* d);  // hode_dopri5.hip
+
 extern "C" int hode_version(void) { return HODE_ABI_VERSION; }
 
 extern "C" const char* hode_last_error_string(void) { return hode::g_err; }
@@ -131,6 +144,8 @@ extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
   switch (which) {
     case HODE_WS_RK_FWD: return 0;
     case HODE_WS_RK_BWD: return (size_t)n_waves_for(d->batch, choose_lpp(d)) * n_partials(d) * sizeof(float);
+    case HODE_WS_DOPRI5_FWD:
+    case HODE_WS_DOPRI5_BWD: return hode_dopri5_workspace_bytes(d);
     default: return 0;
   }
 }
@@ -150,14 +165,11 @@ extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
   const int M = d->latent_dim - 4;
   const int P = n_partials(d);
   const int nw = n_waves_for(d->batch, choose_lpp(d));
-  hipLaunchKernelGGL(hode::fold_partials_kernel, dim3(P), dim3(64), 0, s, (const float*)d->workspace, nw, P,
-                     M * d->latent_dim, M, d->grad_w1, d->grad_b1, d->grad_theta, d->need_theta_grad);
-  return hode::hip_fail(hipGetLastError(), "fold_partials launch");
+  return hode::launch_fold_partials((const float*)d->workspace, nw, P, M * d->latent_dim, M, d->grad_w1, d->grad_b1,
+                                    d->grad_theta, d->need_theta_grad, s);
 }
 
 // not built yet: declared in include/hode.h so the ABI is stable, they report HODE_E_UNSUPPORTED
-extern "C" int hode_dopri5_fwd(const hode_solve_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_dopri5_fwd: not built yet"); }
-extern "C" int hode_dopri5_bwd(const hode_solve_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_dopri5_bwd: not built yet"); }
 extern "C" size_t hode_lstm_workspace_bytes(const hode_lstm_desc*) { return 0; }
 extern "C" int hode_lstm_fwd(const hode_lstm_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_fwd: not built yet"); }
 extern "C" int hode_lstm_bwd(const hode_lstm_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_bwd: not built yet"); }

@@ -1,0 +1,157 @@
+// C-ABI entry points hode_dopri5_fwd / hode_dopri5_bwd (include/hode.h): workspace carving, the attempt loop, checks.
+#include <string.h>
+
+#include "hode_dopri5_kernels.hpp"
+
+namespace {
+
+using hode::DpArgs;
+using hode::DpCtrl;
+using hode::DpLaunch;
+
+constexpr int kChunk = 32;  // attempts enqueued between two reads of the controller record
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct DpLayout {
+  size_t ctrl, partials, kbuf, tape_t, tape_dt, tape_j, tape_y, grad_partials, total;
+};
+
+DpLayout dp_layout(const hode_solve_desc* d) {
+  const int nw = hode::n_waves_for(d->batch, hode::choose_lpp(d));
+  const size_t BD = (size_t)d->batch * d->latent_dim;
+  const size_t S = (size_t)(d->max_steps > 0 ? d->max_steps : 1);
+  DpLayout L;
+  size_t off = 0;
+  L.ctrl = off; off = align_up(off + 2 * sizeof(DpCtrl));
+  L.partials = off; off = align_up(off + (size_t)4 * nw * sizeof(float));
+  L.kbuf = off; off = align_up(off + 7 * BD * sizeof(float));
+  L.tape_t = off; off = align_up(off + S * sizeof(double));
+  L.tape_dt = off; off = align_up(off + S * sizeof(double));
+  L.tape_j = off; off = align_up(off + 2 * S * sizeof(int));
+  L.tape_y = off; off = align_up(off + (S + 1) * BD * sizeof(float));
+  L.grad_partials = off; off = align_up(off + (size_t)nw * hode::n_partials(d) * sizeof(float));
+  L.total = off;
+  return L;
+}
+
+DpArgs dp_args(const hode_solve_desc* d, const DpLayout& L) {
+  DpArgs a{};
+  char* ws = (char*)d->workspace;
+  a.t = d->t; a.y0 = d->y0; a.dosage = d->dosage; a.dose_times = d->dose_times; a.theta = d->theta;
+  a.w1 = d->w1; a.b1 = d->b1; a.h = d->h;
+  a.ctrl = (DpCtrl*)(ws + L.ctrl);
+  a.partials = (float*)(ws + L.partials);
+  a.kbuf = (float*)(ws + L.kbuf);
+  a.tape_t = (double*)(ws + L.tape_t);
+  a.tape_dt = (double*)(ws + L.tape_dt);
+  a.tape_j = (int*)(ws + L.tape_j);
+  a.tape_y = (float*)(ws + L.tape_y);
+  a.grad_h = d->grad_h; a.grad_y0 = d->grad_y0;
+  a.grad_partials = (float*)(ws + L.grad_partials);
+  a.B = d->batch; a.T = d->n_times; a.K = d->n_dose;
+  a.n_waves = hode::n_waves_for(d->batch, hode::choose_lpp(d));
+  a.max_steps = d->max_steps;
+  a.rtol = (float)d->rtol; a.atol = (float)d->atol;
+  return a;
+}
+
+int dp_dispatch_dim(const hode_solve_desc* d, const DpLaunch& L, const DpArgs& a, hipStream_t s) {
+  switch (d->latent_dim) {
+    case 4: return hode::dp_dispatch_d4(L, a, s);
+    case 6: return hode::dp_dispatch_d6(L, a, s);
+    case 8: return hode::dp_dispatch_d8(L, a, s);
+    case 12: return hode::dp_dispatch_d12(L, a, s);
+  }
+  return hode::fail(HODE_E_UNSUPPORTED, "dopri5: latent_dim %d has no compiled kernel (have 4, 6, 8, 12)", d->latent_dim);
+}
+
+int check_dp(const hode_solve_desc* d, bool bwd) {
+  if (!d) return hode::fail(HODE_E_NULL, "descriptor is NULL");
+  if (d->struct_size != sizeof(hode_solve_desc))
+    return hode::fail(HODE_E_SIZE, "struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(hode_solve_desc));
+  if (d->rhs_kind != HODE_RHS_ROCHE && d->rhs_kind != HODE_RHS_ROCHE_ABLATE)
+    return hode::fail(HODE_E_UNSUPPORTED, "rhs_kind %d is not handled by the dopri5 Roche kernels", d->rhs_kind);
+  if (d->batch <= 0 || d->n_times <= 0 || d->latent_dim < 4 || d->n_dose < 0 || d->max_steps <= 0)
+    return hode::fail(HODE_E_SIZE, "bad sizes: batch=%d n_times=%d latent_dim=%d n_dose=%d max_steps=%d", d->batch,
+                      d->n_times, d->latent_dim, d->n_dose, d->max_steps);
+  if (!(d->rtol > 0) || !(d->atol >= 0)) return hode::fail(HODE_E_SIZE, "rtol must be > 0 and atol >= 0");
+  if (!d->t || !d->y0 || !d->dosage || !d->theta || !d->h || (d->n_dose > 0 && !d->dose_times))
+    return hode::fail(HODE_E_NULL, "t / y0 / dosage / dose_times / theta / h must be non-NULL");
+  if (d->latent_dim > 4 && (!d->w1 || !d->b1)) return hode::fail(HODE_E_NULL, "w1 / b1 required when latent_dim > 4");
+  if (!d->host_n_accepted) return hode::fail(HODE_E_NULL, "host_n_accepted is required (fwd: out, bwd: in)");
+  if (bwd && (!d->grad_h || !d->grad_y0)) return hode::fail(HODE_E_NULL, "grad_h / grad_y0 required by the backward");
+  const DpLayout L = dp_layout(d);
+  if (!d->workspace || d->workspace_bytes < L.total)
+    return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, L.total);
+  uintptr_t m = (uintptr_t)d->y0 | (uintptr_t)d->h | (uintptr_t)d->workspace;
+  if (bwd) m |= (uintptr_t)d->grad_h | (uintptr_t)d->grad_y0;
+  if (m & 15) return hode::fail(HODE_E_ALIGN, "y0 / h / grad_h / grad_y0 / workspace must be 16-byte aligned");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t hode_dopri5_workspace_bytes(const hode_solve_desc* d) { return dp_layout(d).total; }
+
+extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
+  if (int e = check_dp(d, false)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  const DpLayout lay = dp_layout(d);
+  DpArgs a = dp_args(d, lay);
+  DpLaunch L;
+  L.lpp = hode::choose_lpp(d);
+  L.ablate = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
+  L.need_th = false;
+  L.phase = 0;
+  if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+  L.phase = 1;
+  if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+  L.phase = 2;
+  DpCtrl host{};
+  int attempt = 0;
+  // every attempt either accepts (<= max_steps of those) or shrinks dt by >= 5x towards underflow: a generous bound
+  const long long max_attempts = 64LL * ((long long)d->max_steps + 64);
+  for (;;) {
+    for (int i = 0; i < kChunk; ++i) {
+      a.attempt = attempt++;
+      if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+    }
+    // the ONE host synchronisation of the path: the number of adaptive steps is data dependent
+    if (int e = hode::hip_fail(hipMemcpyAsync(&host, a.ctrl + (attempt & 1), sizeof(DpCtrl), hipMemcpyDeviceToHost, s),
+                               "controller read-back"))
+      return e;
+    if (int e = hode::hip_fail(hipStreamSynchronize(s), "controller read-back sync")) return e;
+    if (host.done) break;
+    if (attempt > max_attempts) {
+      host.status |= HODE_STATUS_MAX_STEPS;
+      break;
+    }
+  }
+  *d->host_n_accepted = host.n_acc;
+  if (d->host_n_rejected) *d->host_n_rejected = host.n_rej;
+  if (d->status && host.status) {
+    if (int e = hode::hip_fail(hipMemcpyAsync(d->status, &host.status, sizeof(int), hipMemcpyHostToDevice, s), "status write"))
+      return e;
+    if (int e = hode::hip_fail(hipStreamSynchronize(s), "status write sync")) return e;
+  }
+  return 0;
+}
+
+extern "C" int hode_dopri5_bwd(const hode_solve_desc* d, void* stream) {
+  if (int e = check_dp(d, true)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  const DpLayout lay = dp_layout(d);
+  DpArgs a = dp_args(d, lay);
+  a.n_acc = *d->host_n_accepted;
+  if (a.n_acc < 0 || a.n_acc > d->max_steps) return hode::fail(HODE_E_SIZE, "n_accepted %d outside the tape", a.n_acc);
+  DpLaunch L;
+  L.lpp = hode::choose_lpp(d);
+  L.ablate = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
+  L.need_th = d->need_theta_grad != 0;
+  L.phase = 3;
+  if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+  const int M = d->latent_dim - 4;
+  return hode::launch_fold_partials(a.grad_partials, a.n_waves, hode::n_partials(d), M * d->latent_dim, M, d->grad_w1,
+                                    d->grad_b1, d->grad_theta, d->need_theta_grad, s);
+}

@@ -1,0 +1,547 @@
+// Adaptive Dormand-Prince 5(4) solve of the hybrid Roche ODE and its discrete adjoint, gfx950.
+//
+// Replaces torchdiffeq.odeint(method="dopri5") -- the reference default (sim_config.py:50) -- as called at
+// model.py:1116, and the autograd replay of its accepted steps.  CPU restatement: oracle/solvers.py::_odeint_dopri5.
+//
+// Structure: ONE LAUNCH PER ATTEMPTED STEP.  The controller record (t0, dt, counters, done flag)
+// lives in device memory, double-buffered by attempt parity; the batch-global RMS error norm is reduced per wave into
+// a partial array that every wave of the NEXT launch folds in the same fixed order, so every lane takes the same
+// accept/reject decision without atomics or a grid barrier.  The current state y_n is the tape itself
+// (tape_y[n_acc]); a candidate y1 is written to tape_y[n_acc+1] and simply overwritten if the attempt is rejected.
+// Stage derivatives of the latest attempt live in kbuf[7][B][D] (kbuf[0] = f0 of the current state, FSAL).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/hode.h"
+#include "hode_host.hpp"
+#include "hode_lanes.hpp"
+#include "hode_roche.hpp"
+
+namespace hode {
+
+struct DpCtrl {
+  double t0;   // start time of the step being attempted
+  double dt;   // its size
+  float h0, d1;  // Hairer initial-step scratch
+  int n_acc, n_rej, j_next, done, status, attempt;
+};
+
+struct DpArgs {
+  const float* __restrict__ t;
+  const float* __restrict__ y0;
+  const float* __restrict__ dosage;
+  const float* __restrict__ dose_times;
+  const float* __restrict__ theta;
+  const float* __restrict__ w1;
+  const float* __restrict__ b1;
+  float* __restrict__ h;
+  DpCtrl* ctrl;            // [2]
+  float* partials;         // [2][2 * n_waves]
+  float* kbuf;             // [7][B][D]
+  double* tape_t;          // [max_steps]
+  double* tape_dt;         // [max_steps]
+  int* tape_j;             // [2 * max_steps]: first / one-past-last output index interpolated inside the step
+  float* tape_y;           // [max_steps + 1][B][D]
+  const float* __restrict__ grad_h;
+  float* __restrict__ grad_y0;
+  float* __restrict__ grad_partials;  // [n_waves][P]
+  int B, T, K, n_waves, max_steps, attempt, n_acc;
+  float rtol, atol;
+};
+
+// ---- tableau, rounded to fp32 exactly as torchdiffeq casts its float64 tensors to the state dtype
+#define F32(x) ((float)(x))
+__device__ constexpr float kDpAlpha[6] = {F32(1.0 / 5), F32(3.0 / 10), F32(4.0 / 5), F32(8.0 / 9), 1.0f, 1.0f};
+__device__ constexpr float kDpBeta[6][6] = {
+    {F32(1.0 / 5), 0, 0, 0, 0, 0},
+    {F32(3.0 / 40), F32(9.0 / 40), 0, 0, 0, 0},
+    {F32(44.0 / 45), F32(-56.0 / 15), F32(32.0 / 9), 0, 0, 0},
+    {F32(19372.0 / 6561), F32(-25360.0 / 2187), F32(64448.0 / 6561), F32(-212.0 / 729), 0, 0},
+    {F32(9017.0 / 3168), F32(-355.0 / 33), F32(46732.0 / 5247), F32(49.0 / 176), F32(-5103.0 / 18656), 0},
+    {F32(35.0 / 384), 0.0f, F32(500.0 / 1113), F32(125.0 / 192), F32(-2187.0 / 6784), F32(11.0 / 84)},
+};
+__device__ constexpr float kDpErr[7] = {
+    F32(35.0 / 384 - 1951.0 / 21600), 0.0f, F32(500.0 / 1113 - 22642.0 / 50085), F32(125.0 / 192 - 451.0 / 720),
+    F32(-2187.0 / 6784 - -12231.0 / 42400), F32(11.0 / 84 - 649.0 / 6300), F32(-1.0 / 60.0)};
+__device__ constexpr float kDpMid[7] = {
+    F32(6025192743.0 / 30085553152.0 / 2), 0.0f, F32(51252292925.0 / 65400821598.0 / 2),
+    F32(-2691868925.0 / 45128329728.0 / 2), F32(187940372067.0 / 1594534317056.0 / 2),
+    F32(-1776094331.0 / 19743644256.0 / 2), F32(11237099.0 / 235043384.0 / 2)};
+#undef F32
+
+template <bool K1>
+HODE_DEV DoseSched<K1> dp_load_dose(const DpArgs& a, int p) {
+  DoseSched<K1> ds;
+  ds.dosage = a.dosage[p];
+  ds.K = a.K;
+  ds.taus = a.dose_times + (size_t)p * a.K;
+  ds.tau0 = K1 ? ds.taus[0] : 0.f;
+  return ds;
+}
+
+// fold this launch's view of a per-wave partial array (fixed order => identical result in every lane of every wave)
+HODE_DEV float fold_waves(const float* __restrict__ part, int n_waves, int stride, int off) {
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int w = lane; w < n_waves; w += 64) s += part[(size_t)w * stride + off];
+  return wave_sum(s);
+}
+
+// stage time i (2..7) of a step, fp32 like torchdiffeq's _runge_kutta_step; alpha == 1 -> just before t1
+HODE_DEV float dp_stage_time(int i, float t0f, float dtf, float t1f) {
+  const float al = kDpAlpha[i - 2];
+  return al == 1.0f ? nextafter_down(t1f) : add_rn(t0f, mul_rn(al, dtf));
+}
+
+// all seven stage derivatives of one attempt from (y0, k[0] = f0).  Y[i] (i = 1..6) = stage state of stage i+1,
+// Y[6] = y1.  s[i] = this lane's tanh outputs of stage i+1 (s[0] belongs to k[0] and is filled by the caller).
+template <int D, int LPP, bool ABLATE, bool HILL2, bool K1>
+HODE_DEV void dp_stages(const RocheTheta& th, const MlSlice<D, LPP>& ml, const DoseSched<K1>& ds, const float (&y0)[D],
+                        float t0f, float dtf, float t1f, float (&k)[7][D], float (&Y)[7][D],
+                        float (&s)[7][MlSlice<D, LPP>::MR], DoseVal (&dv)[7]) {
+#pragma unroll
+  for (int i = 2; i <= 7; ++i) {
+    const float ti = dp_stage_time(i, t0f, dtf, t1f);
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      float acc = y0[c];
+#pragma unroll
+      for (int m = 0; m < i - 1; ++m) acc = __builtin_fmaf(kDpBeta[i - 2][m] * dtf, k[m][c], acc);
+      Y[i - 1][c] = acc;
+    }
+    dv[i - 1] = ds.at(ti, th.kel);
+    roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dv[i - 1].v, Y[i - 1], k[i - 1], s[i - 1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ init kernels
+// init1: f0 = f(t[0], y0); h[0] = y0; tape_y[0] = y0; kbuf[0] = f0; partial sums of (y0/scale)^2 and (f0/scale)^2
+template <int D, int LPP, bool ABLATE, bool HILL2, bool K1>
+HODE_DEV void dp_init1_body(const DpArgs& a) {
+  using Ml = MlSlice<D, LPP>;
+  const LaneMap<LPP> lm(a.B);
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  Ml ml;
+  ml.load(a.w1, a.b1, lm.q);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  float y[D], f0[D], own[Ml::MR];
+  load_vec<D>(a.y0 + (size_t)lm.p * D, y);
+  roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, ds.at(a.t[0], th.kel).v, y, f0, own);
+  store_vec<D, LPP>(a.h + (size_t)lm.p * D, y, lm.q, lm.live);
+  store_vec<D, LPP>(a.tape_y + (size_t)lm.p * D, y, lm.q, lm.live);
+  store_vec<D, LPP>(a.kbuf + (size_t)lm.p * D, f0, lm.q, lm.live);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const float scale = a.atol + __builtin_fabsf(y[c]) * a.rtol;
+    const float u = div_f32(y[c], scale), v = div_f32(f0[c], scale);
+    s0 = __builtin_fmaf(u, u, s0);
+    s1 = __builtin_fmaf(v, v, s1);
+  }
+  const float m = (lm.live && lm.q == 0) ? 1.0f : 0.0f;  // count every patient once
+  s0 = wave_sum(s0 * m);
+  s1 = wave_sum(s1 * m);
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    a.partials[2 * wave] = s0;
+    a.partials[2 * wave + 1] = s1;
+  }
+}
+
+// init2: h0 from (d0, d1); f1 = f(t0 + h0, y0 + h0 f0); partial of ((f1 - f0)/scale)^2; wave 0 seeds the controller
+template <int D, int LPP, bool ABLATE, bool HILL2, bool K1>
+HODE_DEV void dp_init2_body(const DpArgs& a) {
+  using Ml = MlSlice<D, LPP>;
+  const LaneMap<LPP> lm(a.B);
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  Ml ml;
+  ml.load(a.w1, a.b1, lm.q);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  const float cnt = (float)a.B * (float)D;
+  const float d0 = __builtin_sqrtf(fold_waves(a.partials, a.n_waves, 2, 0) / cnt);
+  const float d1 = __builtin_sqrtf(fold_waves(a.partials, a.n_waves, 2, 1) / cnt);
+  const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : div_f32(0.01f * d0, d1);
+  float y[D], f0[D], y1[D], f1[D], own[Ml::MR];
+  load_vec<D>(a.y0 + (size_t)lm.p * D, y);
+  load_vec<D>(a.kbuf + (size_t)lm.p * D, f0);
+#pragma unroll
+  for (int c = 0; c < D; ++c) y1[c] = __builtin_fmaf(h0, f0[c], y[c]);
+  const float t0f = a.t[0];
+  roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, ds.at(add_rn(t0f, h0), th.kel).v, y1, f1, own);
+  float s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const float scale = a.atol + __builtin_fabsf(y[c]) * a.rtol;
+    const float u = div_f32(f1[c] - f0[c], scale);
+    s2 = __builtin_fmaf(u, u, s2);
+  }
+  s2 = wave_sum(s2 * ((lm.live && lm.q == 0) ? 1.0f : 0.0f));
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  float* pout = a.partials + (size_t)2 * a.n_waves;  // second half: input of attempt 0
+  if ((threadIdx.x & 63) == 0) pout[2 * (gid >> 6)] = s2;
+  if (gid == 0) {
+    DpCtrl c;
+    c.t0 = (double)t0f;
+    c.dt = 0.0;
+    c.h0 = h0;
+    c.d1 = d1;
+    c.n_acc = 0; c.n_rej = 0; c.j_next = 1; c.done = (a.T <= 1) ? 1 : 0; c.status = 0; c.attempt = 0;
+    a.ctrl[0] = c;
+    a.ctrl[1] = c;  // defined contents for the record attempt 0 will fill (its status word is OR-ed into)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attempt kernel
+template <int D, int LPP, bool ABLATE, bool HILL2, bool K1>
+HODE_DEV void dp_attempt_body(const DpArgs& a) {
+  using Ml = MlSlice<D, LPP>;
+  constexpr int MR = Ml::MR;
+  const int par = a.attempt & 1;
+  const DpCtrl cin = a.ctrl[par];
+  DpCtrl* cout = a.ctrl + (par ^ 1);
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cin.done) {
+    if (gid == 0) *cout = cin;
+    return;
+  }
+  // partial layout: init2 wrote attempt 0's input to the second half; attempt k writes half (k & 1), attempt k+1 reads it
+  const float* pin = a.partials + (size_t)(par ^ 1) * 2 * a.n_waves;
+  float* pout = a.partials + (size_t)par * 2 * a.n_waves;
+
+  const LaneMap<LPP> lm(a.B);
+  const size_t row = (size_t)a.B * D;
+  const size_t poff = (size_t)lm.p * D;
+  const float cnt = (float)a.B * (float)D;
+
+  DpCtrl c = cin;
+  float y[D], f0[D];
+  if (cin.attempt == 0) {
+    // finish the initial step selection (order 4): h1 from d1, d2
+    const float d2 = div_f32(__builtin_sqrtf(fold_waves(pin, a.n_waves, 2, 0) / cnt), cin.h0);
+    float h1;
+    if (cin.d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, cin.h0 * 1e-3f);
+    else h1 = powf(div_f32(0.01f, fmaxf(cin.d1, d2)), 0.2f);
+    c.dt = (double)fminf(100.0f * cin.h0, h1);
+    load_vec<D>(a.tape_y + poff, y);
+    load_vec<D>(a.kbuf + poff, f0);
+  } else {
+    const float ratio = __builtin_sqrtf(fold_waves(pin, a.n_waves, 2, 0) / cnt);
+    const bool accept = ratio <= 1.0f;
+    const double t1 = cin.t0 + cin.dt;
+    if (accept) {
+      // candidate becomes the state; emit every output time inside (t0, t1] from the quartic dense output
+      float ya[D], k7[D];
+      load_vec<D>(a.tape_y + (size_t)(cin.n_acc + 1) * row + poff, y);
+      load_vec<D>(a.kbuf + 6 * row + poff, k7);
+      int j = cin.j_next;
+      if (j < a.T && (double)a.t[j] <= t1) {
+        float k1[D], ym[D];
+        load_vec<D>(a.tape_y + (size_t)cin.n_acc * row + poff, ya);
+        load_vec<D>(a.kbuf + poff, k1);
+        const float dtf = (float)cin.dt;
+#pragma unroll
+        for (int cc = 0; cc < D; ++cc) ym[cc] = ya[cc];
+        for (int m = 0; m < 7; ++m) {
+          float km[D];
+          load_vec<D>(a.kbuf + (size_t)m * row + poff, km);
+          const float w = dtf * kDpMid[m];
+#pragma unroll
+          for (int cc = 0; cc < D; ++cc) ym[cc] = __builtin_fmaf(w, km[cc], ym[cc]);
+        }
+        float ca[D], cb[D], cc_[D], cd[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const float f0i = k1[i], f1i = k7[i], y0i = ya[i], y1i = y[i], ymi = ym[i];
+          ca[i] = 2.0f * dtf * (f1i - f0i) - 8.0f * (y1i + y0i) + 16.0f * ymi;
+          cb[i] = dtf * (5.0f * f0i - 3.0f * f1i) + 18.0f * y0i + 14.0f * y1i - 32.0f * ymi;
+          cc_[i] = dtf * (f1i - 4.0f * f0i) - 11.0f * y0i - 5.0f * y1i + 16.0f * ymi;
+          cd[i] = dtf * f0i;
+        }
+        for (; j < a.T && (double)a.t[j] <= t1; ++j) {
+          const float x = (float)(((double)a.t[j] - cin.t0) / (t1 - cin.t0));
+          const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+          float out[D];
+#pragma unroll
+          for (int i = 0; i < D; ++i) out[i] = (((ya[i] + x * cd[i]) + x2 * cc_[i]) + x3 * cb[i]) + x4 * ca[i];
+          store_vec<D, LPP>(a.h + (size_t)j * row + poff, out, lm.q, lm.live);
+        }
+      }
+      if (gid == 0) {
+        a.tape_t[cin.n_acc] = cin.t0;
+        a.tape_dt[cin.n_acc] = cin.dt;
+        a.tape_j[2 * cin.n_acc] = cin.j_next;
+        a.tape_j[2 * cin.n_acc + 1] = j;
+      }
+      c.j_next = j;
+      c.n_acc = cin.n_acc + 1;
+      c.t0 = t1;
+#pragma unroll
+      for (int i = 0; i < D; ++i) f0[i] = k7[i];
+    } else {
+      c.n_rej = cin.n_rej + 1;
+      load_vec<D>(a.tape_y + (size_t)cin.n_acc * row + poff, y);
+      load_vec<D>(a.kbuf + poff, f0);
+    }
+    // controller (torchdiffeq _optimal_step_size): fp64 clock, constants of dopri5 (safety .9, ifactor 10, dfactor .2)
+    double factor;
+    if (ratio == 0.0f) factor = 10.0;
+    else {
+      const double dfac = ratio < 1.0f ? 1.0 : 0.2;
+      const double r = (double)ratio;
+      factor = fmin(10.0, fmax(0.9 / pow(r, 0.2), dfac));
+      if (!(ratio == ratio)) factor = __builtin_nan("");  // torch.max/min propagate NaN
+    }
+    c.dt = cin.dt * factor;
+  }
+  c.attempt = cin.attempt + 1;
+
+  // ---- termination / failure checks (uniform over the grid: every lane computes the same record)
+  bool stop = false;
+  if (c.status) { c.done = 1; stop = true; }  // a lane of the previous attempt flagged a non-finite state
+  if (!stop && c.j_next >= a.T) { c.done = 1; stop = true; }
+  if (!stop && !(c.t0 + c.dt > c.t0)) { c.status |= HODE_STATUS_DT_UNDERFLOW; c.done = 1; stop = true; }
+  if (!stop && c.n_acc >= a.max_steps) { c.status |= HODE_STATUS_MAX_STEPS; c.done = 1; stop = true; }
+  if (stop) {
+    if (gid == 0) *cout = c;
+    return;
+  }
+
+  // ---- new attempt from (y, f0) at (t0, dt)
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  Ml ml;
+  ml.load(a.w1, a.b1, lm.q);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  const float t0f = (float)c.t0, dtf = (float)c.dt, t1f = (float)(c.t0 + c.dt);
+  float k[7][D], Y[7][D], s[7][MR];
+  DoseVal dv[7];
+#pragma unroll
+  for (int i = 0; i < D; ++i) k[0][i] = f0[i];
+  dp_stages<D, LPP, ABLATE, HILL2, K1>(th, ml, ds, y, t0f, dtf, t1f, k, Y, s, dv);
+  float se = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    float err = 0.f;
+#pragma unroll
+    for (int m = 0; m < 7; ++m) err = __builtin_fmaf(dtf * kDpErr[m], k[m][i], err);
+    const float tol = a.atol + a.rtol * fmaxf(__builtin_fabsf(y[i]), __builtin_fabsf(Y[6][i]));
+    const float u = div_f32(err, tol);
+    se = __builtin_fmaf(u, u, se);
+    bad |= !__builtin_isfinite(y[i]);
+  }
+  se = wave_sum(se * ((lm.live && lm.q == 0) ? 1.0f : 0.0f));
+  if ((threadIdx.x & 63) == 0) pout[2 * (gid >> 6)] = se;
+  store_vec<D, LPP>(a.tape_y + (size_t)(c.n_acc + 1) * row + poff, Y[6], lm.q, lm.live);
+#pragma unroll
+  for (int m = 0; m < 7; ++m) store_vec<D, LPP>(a.kbuf + (size_t)m * row + poff, k[m], lm.q, lm.live);
+  if (bad && lm.live) atomicOr(&cout->status, HODE_STATUS_NONFINITE);  // torchdiffeq asserts on the state before a step
+  if (gid == 0) {
+    // status may be OR-ed concurrently by other lanes: write the other fields, OR our own bits
+    cout->t0 = c.t0; cout->dt = c.dt; cout->h0 = c.h0; cout->d1 = c.d1;
+    cout->n_acc = c.n_acc; cout->n_rej = c.n_rej; cout->j_next = c.j_next; cout->done = c.done; cout->attempt = c.attempt;
+    if (c.status) atomicOr(&cout->status, c.status);
+  }
+}
+
+template <int D, int LPP, bool ABLATE, int PHASE>
+__global__ __launch_bounds__(64) void dp_fwd_kernel(DpArgs a) {
+  const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
+#define HODE_DP_DISPATCH(BODY)                                             \
+  if (hill2 && a.K == 1) BODY<D, LPP, ABLATE, true, true>(a);              \
+  else if (hill2) BODY<D, LPP, ABLATE, true, false>(a);                    \
+  else BODY<D, LPP, ABLATE, false, false>(a);
+  if constexpr (PHASE == 0) { HODE_DP_DISPATCH(dp_init1_body) }
+  else if constexpr (PHASE == 1) { HODE_DP_DISPATCH(dp_init2_body) }
+  else { HODE_DP_DISPATCH(dp_attempt_body) }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Reverse sweep over the accepted-step tape.  Per step: recompute the 7 stage derivatives from y_n, then
+//   g7 = lam_f (FSAL use in the next step) + dense-output terms;  a7 = J7^T g7;  lam_y1 += a7
+//   lam_y0 = lam_y1 (+ dense-output terms);  g_m += dt (b_m lam_y1 + cmid_m lam_ymid)
+//   for i = 6..2: a_i = J_i^T g_i; lam_y0 += a_i; g_m += dt beta_{i,m} a_i (m < i)
+//   g1 is handed to step n-1 as lam_f (k1 of step n IS k7 of step n-1); at n = 0 it goes through J1 instead.
+// Step sizes are constants (the controller runs under no_grad in torchdiffeq); the O(tol) dependence of the FIRST
+// step size on the parameters, which torchdiffeq's graph formally contains, is not differentiated.
+template <int D, int LPP, bool ABLATE, bool HILL2, bool NEED_TH, bool K1>
+HODE_DEV void dp_bwd_body(const DpArgs& a) {
+  using Ml = MlSlice<D, LPP>;
+  constexpr int MR = Ml::MR;
+  constexpr int M = D - 4;
+  const LaneMap<LPP> lm(a.B);
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  Ml ml;
+  ml.load(a.w1, a.b1, lm.q);
+  MlColSlice<D, LPP> mc;
+  mc.load(a.w1, lm.q);
+  const float ln_ec50 = log_f32(th.ec50);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  GradAcc<D, LPP> acc;
+  acc.zero();
+  const size_t row = (size_t)a.B * D;
+  const size_t poff = (size_t)lm.p * D;
+  const float live = lm.live ? 1.0f : 0.0f;
+
+  float lam_y[D], lam_f[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) lam_y[i] = lam_f[i] = 0.f;
+
+  for (int n = a.n_acc - 1; n >= 0; --n) {
+    const double t0 = a.tape_t[n], dt = a.tape_dt[n];
+    const double t1 = t0 + dt;
+    const float t0f = (float)t0, dtf = (float)dt, t1f = (float)t1;
+    float y0[D];
+    load_vec<D>(a.tape_y + (size_t)n * row + poff, y0);
+    float k[7][D], Y[7][D], s[7][MR];
+    DoseVal dv[7];
+    const float tk1 = (n == 0) ? a.t[0] : nextafter_down(t0f);
+    dv[0] = ds.at(tk1, th.kel);
+    roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dv[0].v, y0, k[0], s[0]);
+#pragma unroll
+    for (int i = 0; i < D; ++i) Y[0][i] = y0[i];
+    dp_stages<D, LPP, ABLATE, HILL2, K1>(th, ml, ds, y0, t0f, dtf, t1f, k, Y, s, dv);
+
+    float g[7][D], lam_y0[D], lam_mid[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      g[6][i] = lam_f[i];
+      lam_y0[i] = 0.f;
+      lam_mid[i] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) g[m][i] = 0.f;
+    }
+    // cotangents of the outputs interpolated inside this step
+    const int jlo = a.tape_j[2 * n], jhi = a.tape_j[2 * n + 1];
+    for (int j = jlo; j < jhi; ++j) {
+      const float x = (float)(((double)a.t[j] - t0) / (t1 - t0));
+      const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+      const float P0 = 1.0f - 11.0f * x2 + 18.0f * x3 - 8.0f * x4;
+      const float P1 = -5.0f * x2 + 14.0f * x3 - 8.0f * x4;
+      const float Pm = 16.0f * x2 - 32.0f * x3 + 16.0f * x4;
+      const float Q0 = dtf * (x - 4.0f * x2 + 5.0f * x3 - 2.0f * x4);
+      const float Q1 = dtf * (x2 - 3.0f * x3 + 2.0f * x4);
+      float G[D];
+      load_vec<D>(a.grad_h + (size_t)j * row + poff, G);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float gi = G[i] * live;
+        lam_y0[i] = __builtin_fmaf(P0, gi, lam_y0[i]);
+        lam_y[i] = __builtin_fmaf(P1, gi, lam_y[i]);
+        lam_mid[i] = __builtin_fmaf(Pm, gi, lam_mid[i]);
+        g[0][i] = __builtin_fmaf(Q0, gi, g[0][i]);
+        g[6][i] = __builtin_fmaf(Q1, gi, g[6][i]);
+      }
+    }
+    // y_mid = y0 + dt sum cmid_m k_m
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      lam_y0[i] += lam_mid[i];
+#pragma unroll
+      for (int m = 0; m < 7; ++m) g[m][i] = __builtin_fmaf(dtf * kDpMid[m], lam_mid[i], g[m][i]);
+    }
+    // stage 7: k7 = f(t1-, y1)
+    float a_[D];
+    roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, mc, ln_ec50, dv[6], Y[6], s[6], g[6], lm.q, a_, acc);
+#pragma unroll
+    for (int i = 0; i < D; ++i) lam_y[i] += a_[i];
+    // y1 = y0 + dt sum_{m<=6} beta_6m k_m
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      lam_y0[i] += lam_y[i];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) g[m][i] = __builtin_fmaf(kDpBeta[5][m] * dtf, lam_y[i], g[m][i]);
+    }
+    // stages 6 .. 2
+#pragma unroll
+    for (int st = 6; st >= 2; --st) {
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, mc, ln_ec50, dv[st - 1], Y[st - 1], s[st - 1], g[st - 1], lm.q,
+                                                a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        lam_y0[i] += a_[i];
+#pragma unroll
+        for (int m = 0; m < st - 1; ++m) g[m][i] = __builtin_fmaf(kDpBeta[st - 2][m] * dtf, a_[i], g[m][i]);
+      }
+    }
+    if (n == 0) {
+      roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, mc, ln_ec50, dv[0], Y[0], s[0], g[0], lm.q, a_, acc);
+#pragma unroll
+      for (int i = 0; i < D; ++i) lam_y0[i] += a_[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      lam_y[i] = lam_y0[i];
+      lam_f[i] = g[0][i];
+    }
+  }
+  // output 0 is y0 itself
+  {
+    float G[D];
+    load_vec<D>(a.grad_h + poff, G);
+#pragma unroll
+    for (int i = 0; i < D; ++i) lam_y[i] = __builtin_fmaf(G[i], live, lam_y[i]);
+  }
+  store_vec<D, LPP>(a.grad_y0 + poff, lam_y, lm.q, lm.live);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  constexpr int P = M * D + M + kNTheta;
+  float* out = a.grad_partials + (size_t)wave * P;
+  if constexpr (M > 0) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float v = wave_sum_patients<LPP>(acc.dw[r][i]);
+        if (lane < LPP) out[(lane * MR + r) * D + i] = v;
+      }
+      const float vb = wave_sum_patients<LPP>(acc.db[r]);
+      if (lane < LPP) out[M * D + lane * MR + r] = vb;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kNTheta; ++i) {
+    const float v = wave_sum_patients<LPP>(NEED_TH ? acc.dth[i] : 0.f);
+    if (lane == 0) out[M * D + M + i] = v;
+  }
+}
+
+template <int D, int LPP, bool ABLATE, bool NEED_TH>
+__global__ __launch_bounds__(64) void dp_bwd_kernel(DpArgs a) {
+  const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
+  if (hill2 && a.K == 1) dp_bwd_body<D, LPP, ABLATE, true, NEED_TH, true>(a);
+  else if (hill2) dp_bwd_body<D, LPP, ABLATE, true, NEED_TH, false>(a);
+  else dp_bwd_body<D, LPP, ABLATE, false, NEED_TH, false>(a);
+}
+
+// ---------------------------------------------------------------------------------------------- launch helpers
+struct DpLaunch {
+  int lpp;
+  bool ablate, need_th;
+  int phase;  // 0 init1, 1 init2, 2 attempt, 3 backward
+};
+
+template <int D, int LPP, bool ABLATE>
+int dp_launch(const DpLaunch& L, const DpArgs& a, hipStream_t s) {
+  const dim3 grid(a.n_waves), block(64);
+  switch (L.phase) {
+    case 0: hipLaunchKernelGGL((dp_fwd_kernel<D, LPP, ABLATE, 0>), grid, block, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((dp_fwd_kernel<D, LPP, ABLATE, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((dp_fwd_kernel<D, LPP, ABLATE, 2>), grid, block, 0, s, a); break;
+    case 3:
+      if (L.need_th) hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, false>), grid, block, 0, s, a);
+      break;
+  }
+  return (int)hipGetLastError();
+}
+
+template <int D>
+int dp_dispatch(const DpLaunch& L, const DpArgs& a, hipStream_t s) {
+  if constexpr (D > 4 && (D - 4) % 4 == 0) {
+    if (L.lpp == 4) return L.ablate ? dp_launch<D, 4, true>(L, a, s) : dp_launch<D, 4, false>(L, a, s);
+  }
+  return L.ablate ? dp_launch<D, 1, true>(L, a, s) : dp_launch<D, 1, false>(L, a, s);
+}
+
+}  // namespace hode

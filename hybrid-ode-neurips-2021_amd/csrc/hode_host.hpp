@@ -39,4 +39,21 @@ int rk_dispatch_d8(const RkLaunch&, const RkArgs&, hipStream_t);
 int rk_dispatch_d12(const RkLaunch&, const RkArgs&, hipStream_t);
 int rk_dispatch_d20(const RkLaunch&, const RkArgs&, hipStream_t);
 
+// dopri5: one entry per compiled latent dimension (hode_dopri5_dim.hip, -DHODE_DIM=<D>)
+struct DpArgs;
+struct DpLaunch;
+int dp_dispatch_d4(const DpLaunch&, const DpArgs&, hipStream_t);
+int dp_dispatch_d6(const DpLaunch&, const DpArgs&, hipStream_t);
+int dp_dispatch_d8(const DpLaunch&, const DpArgs&, hipStream_t);
+int dp_dispatch_d12(const DpLaunch&, const DpArgs&, hipStream_t);
+
+// shared host helpers (hode_api.hip)
+int hip_fail(hipError_t e, const char* what);
+int n_waves_for(int B, int lpp);
+int choose_lpp(const hode_solve_desc* d);
+int n_partials(const hode_solve_desc* d);
+// out += fixed-order sum over waves of partials[w][0..P): [w1 | b1 | theta]
+int launch_fold_partials(const float* partials, int n_waves, int P, int n_w, int n_b, float* gw, float* gb, float* gth,
+                         int need_th, hipStream_t s);
+
 }  // namespace hode

@@ -1,0 +1,112 @@
+"""dopri5 drop-in: ``torchdiffeq.odeint(method="dopri5")`` semantics (reference default, ``sim_config.py:50``) on the
+gfx950 kernels (``hode_dopri5_fwd`` / ``hode_dopri5_bwd``).
+
+One launch per attempted step with the controller resident on the device; the library reads the controller record
+back once per chunk of attempts (the step count is data dependent).  Accepted steps form a tape inside the
+workspace tensor, which the autograd node keeps alive for the backward sweep.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .solver import _f32c, _ptr, _require_gpu, _stream
+
+#: last forward's step statistics (diagnostics; mirrors what torchdiffeq exposes through nfe counters)
+last_stats = {"n_accepted": 0, "n_rejected": 0}
+
+
+def _status_error(status):
+    msgs = []
+    if status & L.STATUS_NONFINITE:
+        msgs.append("non-finite values in state `y`")
+    if status & L.STATUS_DT_UNDERFLOW:
+        msgs.append("underflow in dt")
+    return "; ".join(msgs)
+
+
+class _RocheDopri5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, theta, w, b, t, dosage, dose_times, rtol, atol, ablate, lanes, max_steps):
+        _require_gpu(y0, theta, t, dosage, dose_times)
+        lib = L.lib()
+        B, D = y0.shape
+        T = t.numel()
+        y0c, thc, tc = _f32c(y0), _f32c(theta), _f32c(t)
+        dosc, dtc = _f32c(dosage), _f32c(dose_times)
+        wc = _f32c(w) if w is not None else None
+        bc = _f32c(b) if b is not None else None
+        h = torch.empty((T, B, D), device=y0.device, dtype=torch.float32)
+        steps = int(max_steps) if max_steps else 16 * T + 64
+        while True:
+            status = torch.zeros(1, device=y0.device, dtype=torch.int32)
+            n_acc, n_rej = C.c_int32(0), C.c_int32(0)
+            d = L.new_solve_desc()
+            d.rhs_kind = L.RHS_ROCHE_ABLATE if ablate else L.RHS_ROCHE
+            d.batch, d.latent_dim, d.n_times = B, D, T
+            d.n_dose = dtc.shape[1] if dtc.dim() == 2 else 0
+            d.lanes_per_patient = lanes
+            d.t, d.y0, d.dosage, d.dose_times, d.theta = tc.data_ptr(), y0c.data_ptr(), dosc.data_ptr(), _ptr(dtc), thc.data_ptr()
+            d.w1, d.b1, d.h, d.status = _ptr(wc), _ptr(bc), h.data_ptr(), status.data_ptr()
+            d.rtol, d.atol, d.max_steps = float(rtol), float(atol), steps
+            d.host_n_accepted, d.host_n_rejected = C.pointer(n_acc), C.pointer(n_rej)
+            nbytes = lib.hode_workspace_bytes(d, L.WS_DOPRI5_FWD)
+            ws = torch.empty(nbytes, device=y0.device, dtype=torch.uint8)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+            with torch.cuda.device(y0.device):
+                L.check(lib.hode_dopri5_fwd(d, _stream()), "hode_dopri5_fwd")
+            st = int(status.item())
+            if st & L.STATUS_MAX_STEPS and not (st & (L.STATUS_NONFINITE | L.STATUS_DT_UNDERFLOW)) and steps < (1 << 20):
+                steps *= 4  # tape too small: retry with a larger one
+                continue
+            break
+        last_stats.update(n_accepted=n_acc.value, n_rejected=n_rej.value)
+        if st:
+            # torchdiffeq raises AssertionError here, which the reference's training loop does NOT catch; a RuntimeError
+            # subclass lets `except RuntimeError` (training_utils.py:45) end the diverged restart instead.
+            raise L.HodeError("hode dopri5: " + (_status_error(st) or "max_num_steps exceeded"))
+        ctx.save_for_backward(h, thc, wc if wc is not None else thc, bc if bc is not None else thc, tc, dosc, dtc, y0c, ws)
+        ctx.meta = (float(rtol), float(atol), bool(ablate), int(lanes), w is not None, steps, n_acc.value)
+        return h
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        h, thc, wc, bc, tc, dosc, dtc, y0c, ws = ctx.saved_tensors
+        rtol, atol, ablate, lanes, has_w, steps, n_accepted = ctx.meta
+        lib = L.lib()
+        T, B, D = h.shape
+        gh = grad_h.to(torch.float32).contiguous()
+        need_th = bool(ctx.needs_input_grad[1])
+        gy0 = torch.empty((B, D), device=h.device, dtype=torch.float32)
+        gth = torch.zeros(L.N_THETA, device=h.device, dtype=torch.float32)
+        gw = torch.zeros_like(wc) if has_w else None
+        gb = torch.zeros_like(bc) if has_w else None
+        n_acc = C.c_int32(n_accepted)
+        d = L.new_solve_desc()
+        d.rhs_kind = L.RHS_ROCHE_ABLATE if ablate else L.RHS_ROCHE
+        d.batch, d.latent_dim, d.n_times = B, D, T
+        d.n_dose = dtc.shape[1] if dtc.dim() == 2 else 0
+        d.lanes_per_patient = lanes
+        d.need_theta_grad = int(need_th)
+        d.t, d.y0, d.dosage, d.dose_times, d.theta = tc.data_ptr(), y0c.data_ptr(), dosc.data_ptr(), _ptr(dtc), thc.data_ptr()
+        d.w1, d.b1, d.h = (_ptr(wc), _ptr(bc), h.data_ptr()) if has_w else (0, 0, h.data_ptr())
+        d.grad_h, d.grad_y0 = gh.data_ptr(), gy0.data_ptr()
+        d.grad_w1, d.grad_b1, d.grad_theta = _ptr(gw), _ptr(gb), gth.data_ptr()
+        d.rtol, d.atol, d.max_steps = rtol, atol, steps
+        d.host_n_accepted = C.pointer(n_acc)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        with torch.cuda.device(h.device):
+            L.check(lib.hode_dopri5_bwd(d, _stream()), "hode_dopri5_bwd")
+        return gy0, (gth if need_th else None), gw, gb, None, None, None, None, None, None, None, None
+
+
+def roche_dopri5(y0, theta, w, b, t, dosage, dose_times, rtol=1e-7, atol=1e-9, ablate=False, lanes_per_patient=0,
+                 max_steps=0):
+    """Adaptive solve of the Roche rhs; returns h (T, B, D).  Arguments as ``hode.roche_solve``."""
+    if dose_times.dim() != 2:
+        dose_times = dose_times.reshape(y0.shape[0], -1)
+    return _RocheDopri5.apply(y0, theta, w, b, t, dosage, dose_times.to(torch.float32), rtol, atol, bool(ablate),
+                              int(lanes_per_patient), int(max_steps))

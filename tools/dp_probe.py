@@ -1,0 +1,12 @@
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "hybrid-ode-neurips-2021_amd")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch
+import test_hip_dopri5 as T
+dev = torch.device("cuda:0")
+for (D, lanes, nodose, rtol) in [(12,4,False,1e-7),(12,1,False,1e-7),(8,4,False,1e-7),(4,1,False,1e-7),(12,4,True,1e-6),(12,4,True,1e-7)]:
+    inp, f = T._setup(21, 20, D, seed=40+D)
+    if nodose: inp["actions"].zero_()
+    cot = torch.randn(20, 21, D, generator=torch.Generator().manual_seed(3))
+    hip, ora = T._hip(inp, f, dev, lanes, rtol, 1e-8, cot), T._oracle(inp, f, rtol, 1e-8, cot)
+    print(D, lanes, nodose, rtol, hip["stats"], ora["stats"]["n_accepted"], ora["stats"]["n_rejected"],
+          "maxabs %.3e" % (hip["h"]-ora["h"]).abs().max().item(), {k: "%.2e" % T._rel(hip[k], ora[k]) for k in ("gy0","gw","gb","gtheta") if k in ora})
