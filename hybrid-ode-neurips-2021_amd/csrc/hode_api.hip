@@ -168,8 +168,3 @@ extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
   return hode::launch_fold_partials((const float*)d->workspace, nw, P, M * d->latent_dim, M, d->grad_w1, d->grad_b1,
                                     d->grad_theta, d->need_theta_grad, s);
 }
-
-// not built yet: declared in include/hode.h so the ABI is stable, they report HODE_E_UNSUPPORTED
-extern "C" size_t hode_lstm_workspace_bytes(const hode_lstm_desc*) { return 0; }
-extern "C" int hode_lstm_fwd(const hode_lstm_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_fwd: not built yet"); }
-extern "C" int hode_lstm_bwd(const hode_lstm_desc*, void*) { return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_bwd: not built yet"); }

@@ -1,0 +1,386 @@
+// Masked single-layer LSTM over an observation window on the matrix cores (fp32 MFMA), gfx950.
+//
+// Replaces the T single-step nn.LSTM calls of EncoderLSTM.forward (reference model.py:420-422; EncoderLSTMReal
+// :226-229) and fuses the cat([x, a]) * cat([mask, 1]) that feeds them (model.py:415-421).  CPU restatement:
+// oracle/encoder.py::lstm_cell.  Gate order i, f, g, o; gates = x W_ih^T + b_ih + h W_hh^T + b_hh.
+//
+// Design.  A workgroup (4 waves) owns a tile of BT = 16*NT patients for the WHOLE window:
+// h and c never leave the chip.  Per step the gate pre-activations G^T[4H x BT] = Wcat[4H x K] * act^T[K x BT]
+// (K = I + H) are accumulated with v_mfma_f32_16x16x4_f32 -- exact fp32, the matrix pipe's rate for this dtype.
+//   * Wcat is the A operand.  Its rows are permuted so that one 16-row MFMA tile = 4 hidden units x 4 gates; in the
+//     16x16 accumulator layout (row = 4*(lane>>4) + reg, col = lane&15) a lane then holds all four gates of ONE
+//     (unit, patient) pair in its 4 registers: the cell update needs no cross-lane traffic at all.
+//     Wave w owns hidden units [w*H/4, (w+1)*H/4); its quarter of Wcat is streamed from L2 every step as
+//     pre-packed fragments (one global_load_dwordx4 per lane = 4 k-quads of one tile; 1 KiB per wave-instruction).
+//   * act^T (B operand) lives in LDS k-major ([k][patient], leading dimension == 16 mod 32 so the 4x16 fragment
+//     read is bank-conflict free), double buffered: x_t*mask_t for the next step is fetched from HBM (coalesced,
+//     contiguous tile) while the current step's MFMAs run; h_t is written by the cell update.
+// Algorithmic bytes per patient: 2*4*T*obs (x, mask) + 4*T*(I-obs) read, 8H written; with save_tape additionally
+// 20*T*H written (activated gates + cell state per step, in the lane order the backward kernel reads them).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "../../include/hode.h"
+#include "hode_common.hpp"
+#include "hode_host.hpp"
+
+namespace hode {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LstmArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ a;
+  const float* __restrict__ mask;
+  const float* __restrict__ wp;     // packed Wcat fragments [4][KQ4][TPW][64][4]
+  const float* __restrict__ bp;     // packed bias [4][TPW][64][4]
+  float* __restrict__ h_out;
+  float* __restrict__ c_out;
+  float* __restrict__ tape;         // [T][nblk][4][TPW][NT][5][64] or nullptr
+  int T, B, OBS, AD, I, H, Hp, Kq, KQ4, LD, reverse;
+};
+
+HODE_DEV float sigmoid_gate(float x) {
+  // 1 / (1 + exp(-x)) on v_exp + v_rcp (<= 2 ulp); exp overflow -> rcp(inf) = 0, underflow -> 1
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+// ---- weight / bias packing (once per forward: the optimiser changes the weights every step)
+__global__ void lstm_pack_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh, float* __restrict__ wp,
+                                 float* __restrict__ bp, int I, int H, int TPW, int KQ4) {
+  const long long n_w = 4LL * KQ4 * TPW * 64 * 4;
+  const long long n_b = 4LL * TPW * 64 * 4;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n_w + n_b;
+       idx += (long long)gridDim.x * blockDim.x) {
+    if (idx < n_w) {
+      const int kk = idx & 3;
+      const int l = (idx >> 2) & 63;
+      long long r = idx >> 8;
+      const int tau = (int)(r % TPW); r /= TPW;
+      const int kq4 = (int)(r % KQ4);
+      const int w = (int)(r / KQ4);
+      const int i = l & 15;
+      const int u = (w * TPW + tau) * 4 + (i >> 2);
+      const int gate = i & 3;
+      const int k = 4 * (4 * kq4 + kk) + (l >> 4);
+      float v = 0.f;
+      if (u < H) {
+        const int row = gate * H + u;
+        if (k < I) v = w_ih[(size_t)row * I + k];
+        else if (k - I < H) v = w_hh[(size_t)row * H + (k - I)];
+      }
+      wp[idx] = v;
+    } else {
+      const long long j = idx - n_w;
+      const int gate = j & 3;
+      const int l = (j >> 2) & 63;
+      long long r = j >> 8;
+      const int tau = (int)(r % TPW);
+      const int w = (int)(r / TPW);
+      const int u = (w * TPW + tau) * 4 + (l >> 4);
+      bp[j] = u < H ? b_ih[gate * H + u] + b_hh[gate * H + u] : 0.f;
+    }
+  }
+}
+
+// ---- forward
+template <int NT, int TPW>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BT = 16 * NT;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int g = l >> 4, pc = l & 15;
+  const int b0 = blockIdx.x * BT;
+  const int nvalid = min(BT, p.B - b0);
+  const int LD = p.LD;
+  const int Krows = 4 * p.Kq;                  // rows of one activation buffer (zero padded past I + Hp)
+  float* act0 = lds;
+  float* act1 = lds + (size_t)Krows * LD;
+
+  // zero both activation buffers (h_{-1} = 0, padding rows/columns stay 0 forever)
+  for (int e = tid; e < 2 * Krows * LD; e += 256) lds[e] = 0.f;
+
+  // bias-initialised accumulators are rebuilt every step from these registers
+  f32x4 bias[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) bias[t] = *reinterpret_cast<const f32x4*>(p.bp + ((size_t)(w * TPW + t) * 64 + l) * 4);
+  float cst[TPW][NT];
+  float hlast[TPW][NT];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int c = 0; c < NT; ++c) cst[t][c] = hlast[t][c] = 0.f;
+
+  // x tile staging: the tile of one step is BT*OBS contiguous floats (patients are contiguous in [T][B][OBS])
+  constexpr int XPT = 20;  // staged elements per thread (covers BT*OBS <= 5120)
+  const int n_x = nvalid * p.OBS;
+  float xs[XPT];
+  auto fetch_x = [&](int t) {
+    const size_t base = ((size_t)t * p.B + b0) * p.OBS;
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int e = tid + 256 * j;
+      float v = 0.f;
+      if (e < n_x) {
+        v = p.x[base + e];
+        if (p.mask) v *= p.mask[base + e];
+      }
+      xs[j] = v;
+    }
+  };
+  auto stage_x = [&](float* dst, int t) {
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int e = tid + 256 * j;
+      if (e < n_x) {
+        const int b = e / p.OBS, i = e - b * p.OBS;
+        dst[i * LD + b] = xs[j];
+      }
+    }
+    // action columns (never masked): AD * nvalid values
+    for (int e = tid; e < nvalid * p.AD; e += 256) {
+      const int b = e / p.AD, i = e - b * p.AD;
+      dst[(p.OBS + i) * LD + b] = p.a[((size_t)t * p.B + b0 + b) * p.AD + i];
+    }
+  };
+
+  const int t_first = p.reverse ? p.T - 1 : 0;
+  fetch_x(t_first);
+  __syncthreads();  // zero fill done
+  stage_x(act0, t_first);
+  __syncthreads();
+
+  const f32x4* wbase = reinterpret_cast<const f32x4*>(p.wp) + (size_t)w * p.KQ4 * TPW * 64 + l;
+
+  for (int s = 0; s < p.T; ++s) {
+    const int t = p.reverse ? p.T - 1 - s : s;
+    float* cur = (s & 1) ? act1 : act0;
+    float* nxt = (s & 1) ? act0 : act1;
+    const bool more = s + 1 < p.T;
+    const int t_next = p.reverse ? t - 1 : t + 1;
+    if (more) fetch_x(t_next);  // HBM loads in flight under the MFMA loop
+
+    f32x4 acc[TPW][NT];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+      for (int c = 0; c < NT; ++c) acc[tt][c] = bias[tt];
+
+    // software-pipelined weight fragments: group q+1 is loaded while group q feeds the matrix pipe
+    f32x4 wa[TPW], wb[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) wa[tt] = wbase[(size_t)tt * 64];
+    for (int q = 0; q < p.KQ4; ++q) {
+      const bool has_next = q + 1 < p.KQ4;
+      if (has_next) {
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) wb[tt] = wbase[((size_t)(q + 1) * TPW + tt) * 64];
+      }
+      const int kq_lim = min(4, p.Kq - 4 * q);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < kq_lim) {
+          const float* rowp = cur + (size_t)(4 * (4 * q + kk) + g) * LD + pc;
+          float bf[NT];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bf[c] = rowp[16 * c];
+#pragma unroll
+          for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+              acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tt][kk], bf[c], acc[tt][c], 0, 0, 0);
+        }
+      }
+      if (has_next) {
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) wa[tt] = wb[tt];
+      }
+    }
+
+    // cell update: lane (g, pc) holds gates i,f,g,o of unit u = (w*TPW + tt)*4 + g for patient 16c + pc
+    float* tp = p.tape ? p.tape + (((size_t)t * gridDim.x + blockIdx.x) * 4 + w) * TPW * NT * 5 * 64 + l : nullptr;
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      const int u = (w * TPW + tt) * 4 + g;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const float gi = sigmoid_gate(acc[tt][c][0]);
+        const float gf = sigmoid_gate(acc[tt][c][1]);
+        const float gg = tanh_f32(acc[tt][c][2]);
+        const float go = sigmoid_gate(acc[tt][c][3]);
+        const float cn = __builtin_fmaf(gf, cst[tt][c], gi * gg);
+        const float hn = go * tanh_f32(cn);
+        cst[tt][c] = cn;
+        hlast[tt][c] = hn;
+        nxt[(size_t)(p.I + u) * LD + 16 * c + pc] = hn;
+        if (tp) {
+          float* q5 = tp + (size_t)(tt * NT + c) * 5 * 64;
+          q5[0] = gi; q5[64] = gf; q5[128] = gg; q5[192] = go; q5[256] = cn;
+        }
+      }
+    }
+    if (more) stage_x(nxt, t_next);
+    __syncthreads();
+  }
+
+  // final state
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int u = (w * TPW + tt) * 4 + g;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int b = 16 * c + pc;
+      if (u < p.H && b < nvalid) {
+        p.h_out[(size_t)(b0 + b) * p.H + u] = hlast[tt][c];
+        p.c_out[(size_t)(b0 + b) * p.H + u] = cst[tt][c];
+      }
+    }
+  }
+}
+
+}  // namespace hode
+
+// ====================================================================================================== host
+namespace {
+
+using hode::LstmArgs;
+
+struct LstmGeom {
+  int Hp, TPW, NT, BT, nblk, Kq, KQ4, LD;
+  size_t wp_floats, bp_floats, tape_floats, lds_bytes;
+};
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+// patients per workgroup: the smallest cost rounds(blocks over 256 CUs) * NT, ties to the larger tile
+int choose_nt(int B, bool bwd) {
+  int best = 1;
+  long long best_cost = -1;
+  for (int nt = 1; nt <= (bwd ? 3 : 4); ++nt) {
+    const long long blocks = (B + 16 * nt - 1) / (16 * nt);
+    const long long cost = ((blocks + 255) / 256) * nt;
+    if (best_cost < 0 || cost <= best_cost) { best = nt; best_cost = cost; }
+  }
+  return best;
+}
+
+int lstm_geom(const hode_lstm_desc* d, LstmGeom* G) {
+  const int Hp = (d->hidden_dim + 15) / 16 * 16;
+  G->Hp = Hp;
+  G->TPW = Hp / 16;
+  if (G->TPW != 3 && G->TPW != 5 && G->TPW != 10)
+    return hode::fail(HODE_E_UNSUPPORTED, "lstm: hidden_dim %d (padded %d) has no compiled kernel (padded H in {48, 80, 160})",
+                      d->hidden_dim, Hp);
+  G->NT = choose_nt(d->batch, false);
+  if (const char* env = getenv("HODE_LSTM_NT")) {  // tuning / test override of the patient tile (16 * NT)
+    const int v = atoi(env);
+    if (v >= 1 && v <= 4) G->NT = v;
+  }
+  G->BT = 16 * G->NT;
+  G->nblk = (d->batch + G->BT - 1) / G->BT;
+  G->Kq = (d->input_dim + Hp + 3) / 4;
+  G->KQ4 = (G->Kq + 3) / 4;
+  G->LD = G->BT + ((G->BT % 32 == 0) ? 16 : 0);
+  G->wp_floats = (size_t)4 * G->KQ4 * G->TPW * 64 * 4;
+  G->bp_floats = (size_t)4 * G->TPW * 64 * 4;
+  G->tape_floats = (size_t)d->seq_len * G->nblk * 4 * G->TPW * G->NT * 5 * 64;
+  G->lds_bytes = (size_t)2 * 4 * G->Kq * G->LD * sizeof(float);
+  if (G->lds_bytes > 160 * 1024)
+    return hode::fail(HODE_E_UNSUPPORTED, "lstm: activation tile needs %zu B of LDS (> 160 KiB)", G->lds_bytes);
+  while (G->NT > 1 && (size_t)16 * G->NT * d->obs_dim > 5120) --G->NT;
+  G->BT = 16 * G->NT;
+  G->nblk = (d->batch + G->BT - 1) / G->BT;
+  G->LD = G->BT + ((G->BT % 32 == 0) ? 16 : 0);
+  G->tape_floats = (size_t)d->seq_len * G->nblk * 4 * G->TPW * G->NT * 5 * 64;
+  G->lds_bytes = (size_t)2 * 4 * G->Kq * G->LD * sizeof(float);
+  if ((size_t)G->BT * d->obs_dim > 5120)
+    return hode::fail(HODE_E_UNSUPPORTED, "lstm: obs_dim %d too wide for the staging registers", d->obs_dim);
+  return 0;
+}
+
+int check_lstm(const hode_lstm_desc* d) {
+  if (!d) return hode::fail(HODE_E_NULL, "descriptor is NULL");
+  if (d->struct_size != sizeof(hode_lstm_desc))
+    return hode::fail(HODE_E_SIZE, "struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(hode_lstm_desc));
+  if (d->seq_len <= 0 || d->batch <= 0 || d->input_dim <= 0 || d->hidden_dim <= 0 || d->obs_dim <= 0 ||
+      d->obs_dim > d->input_dim)
+    return hode::fail(HODE_E_SIZE, "bad sizes: T=%d B=%d I=%d H=%d obs=%d", d->seq_len, d->batch, d->input_dim,
+                      d->hidden_dim, d->obs_dim);
+  if (!d->x || !d->w_ih || !d->w_hh || !d->b_ih || !d->b_hh || !d->h_out || !d->c_out)
+    return hode::fail(HODE_E_NULL, "x / w_ih / w_hh / b_ih / b_hh / h_out / c_out must be non-NULL");
+  if (d->input_dim > d->obs_dim && !d->a) return hode::fail(HODE_E_NULL, "a is required when input_dim > obs_dim");
+  return 0;
+}
+
+template <int NT>
+int launch_fwd_tpw(const LstmGeom& G, const LstmArgs& a, hipStream_t s) {
+  const dim3 grid(G.nblk), block(256);
+  switch (G.TPW) {
+    case 3: hipLaunchKernelGGL((hode::lstm_fwd_kernel<NT, 3>), grid, block, G.lds_bytes, s, a); break;
+    case 5: hipLaunchKernelGGL((hode::lstm_fwd_kernel<NT, 5>), grid, block, G.lds_bytes, s, a); break;
+    case 10: hipLaunchKernelGGL((hode::lstm_fwd_kernel<NT, 10>), grid, block, G.lds_bytes, s, a); break;
+  }
+  return hode::hip_fail(hipGetLastError(), "lstm_fwd launch");
+}
+
+template <int NT, int TPW>
+int set_lds_attr(size_t bytes) {
+  return hode::hip_fail(hipFuncSetAttribute((const void*)hode::lstm_fwd_kernel<NT, TPW>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+}
+
+template <int NT>
+int set_lds_attr_tpw(const LstmGeom& G) {
+  switch (G.TPW) {
+    case 3: return set_lds_attr<NT, 3>(G.lds_bytes);
+    case 5: return set_lds_attr<NT, 5>(G.lds_bytes);
+    case 10: return set_lds_attr<NT, 10>(G.lds_bytes);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t hode_lstm_workspace_bytes(const hode_lstm_desc* d) {
+  LstmGeom G;
+  if (!d || d->struct_size != sizeof(hode_lstm_desc) || lstm_geom(d, &G)) return 0;
+  size_t n = align256(G.wp_floats * 4) + align256(G.bp_floats * 4);
+  if (d->save_tape) n += align256(G.tape_floats * 4);
+  return n;
+}
+
+extern "C" int hode_lstm_fwd(const hode_lstm_desc* d, void* stream) {
+  if (int e = check_lstm(d)) return e;
+  LstmGeom G;
+  if (int e = lstm_geom(d, &G)) return e;
+  const size_t need = hode_lstm_workspace_bytes(d);
+  if (!d->workspace || d->workspace_bytes < need)
+    return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)d->workspace;
+  float* wp = (float*)ws;
+  float* bp = (float*)(ws + align256(G.wp_floats * 4));
+  float* tape = d->save_tape ? (float*)(ws + align256(G.wp_floats * 4) + align256(G.bp_floats * 4)) : nullptr;
+  hipLaunchKernelGGL(hode::lstm_pack_kernel, dim3(256), dim3(256), 0, s, d->w_ih, d->w_hh, d->b_ih, d->b_hh, wp, bp,
+                     d->input_dim, d->hidden_dim, G.TPW, G.KQ4);
+  if (int e = hode::hip_fail(hipGetLastError(), "lstm_pack launch")) return e;
+  LstmArgs a{};
+  a.x = d->x; a.a = d->a; a.mask = d->mask; a.wp = wp; a.bp = bp; a.h_out = d->h_out; a.c_out = d->c_out; a.tape = tape;
+  a.T = d->seq_len; a.B = d->batch; a.OBS = d->obs_dim; a.AD = d->input_dim - d->obs_dim; a.I = d->input_dim;
+  a.H = d->hidden_dim; a.Hp = G.Hp; a.Kq = G.Kq; a.KQ4 = G.KQ4; a.LD = G.LD; a.reverse = d->reverse;
+  int e = 0;
+  switch (G.NT) {
+    case 1: e = set_lds_attr_tpw<1>(G); if (!e) e = launch_fwd_tpw<1>(G, a, s); break;
+    case 2: e = set_lds_attr_tpw<2>(G); if (!e) e = launch_fwd_tpw<2>(G, a, s); break;
+    case 3: e = set_lds_attr_tpw<3>(G); if (!e) e = launch_fwd_tpw<3>(G, a, s); break;
+    case 4: e = set_lds_attr_tpw<4>(G); if (!e) e = launch_fwd_tpw<4>(G, a, s); break;
+  }
+  return e;
+}
+
+extern "C" int hode_lstm_bwd(const hode_lstm_desc*, void*) {
+  return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_bwd: not built yet");
+}

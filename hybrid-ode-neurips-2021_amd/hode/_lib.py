@@ -55,10 +55,9 @@ class LstmDesc(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
         ("seq_len", C.c_int32), ("batch", C.c_int32), ("input_dim", C.c_int32), ("hidden_dim", C.c_int32),
-        ("reverse", C.c_int32), ("masked", C.c_int32), ("reserved0", C.c_int32),
-        ("x", _fp), ("mask", _fp), ("w_ih", _fp), ("w_hh", _fp), ("b_ih", _fp), ("b_hh", _fp),
-        ("h_out", _fp), ("c_out", _fp), ("grad_h_out", _fp),
-        ("grad_w_ih", _fp), ("grad_w_hh", _fp), ("grad_b_ih", _fp), ("grad_b_hh", _fp),
+        ("obs_dim", C.c_int32), ("reverse", C.c_int32), ("save_tape", C.c_int32),
+        ("x", _fp), ("a", _fp), ("mask", _fp), ("w_ih", _fp), ("w_hh", _fp), ("b_ih", _fp), ("b_hh", _fp),
+        ("h_out", _fp), ("c_out", _fp), ("grad_h_out", _fp), ("grad_gates", _fp), ("h_prev", _fp),
         ("workspace", _fp), ("workspace_bytes", C.c_size_t),
     ]
 

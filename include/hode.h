@@ -125,18 +125,21 @@ typedef struct hode_solve_desc {
   size_t workspace_bytes;
 } hode_solve_desc;
 
-/* LSTM encoder (reference EncoderLSTM.forward model.py:408-428, EncoderLSTMReal.forward :210-242) */
+/* LSTM encoder (reference EncoderLSTM.forward model.py:408-428, EncoderLSTMReal.forward :210-242).
+ * The kernel fuses the reference's cat([x, a]) * cat([mask, 1]) (model.py:415-421): x and mask cover the first
+ * obs_dim input columns, a the remaining input_dim - obs_dim (never masked). */
 typedef struct hode_lstm_desc {
   uint32_t struct_size;
   int32_t seq_len;     /* T */
   int32_t batch;       /* B */
-  int32_t input_dim;   /* I = obs + action (+ statics + 1) */
+  int32_t input_dim;   /* I = obs_dim + action columns */
   int32_t hidden_dim;  /* H */
+  int32_t obs_dim;     /* columns taken from x (and masked); the other I - obs_dim come from a */
   int32_t reverse;     /* 1: walk t = T-1 .. 0 (EncoderLSTM, model.py:420); 0: forward (EncoderLSTMReal) */
-  int32_t masked;      /* 1: input = x*mask (model.py:421) */
-  int32_t reserved0;
-  const float* x;      /* [T][B][I] */
-  const float* mask;   /* [T][B][I] or NULL */
+  int32_t save_tape;   /* forward: 1 = write the gate/cell tape into workspace for hode_lstm_bwd */
+  const float* x;      /* [T][B][obs_dim] */
+  const float* a;      /* [T][B][I - obs_dim] or NULL when I == obs_dim */
+  const float* mask;   /* [T][B][obs_dim] or NULL (no masking) */
   const float* w_ih;   /* [4H][I]  gate order i,f,g,o (nn.LSTM) */
   const float* w_hh;   /* [4H][H] */
   const float* b_ih;   /* [4H] */
@@ -144,12 +147,10 @@ typedef struct hode_lstm_desc {
   float* h_out;        /* [B][H] final hidden state */
   float* c_out;        /* [B][H] final cell state */
   /* backward */
-  const float* grad_h_out; /* [B][H] */
-  float* grad_w_ih;    /* acc */
-  float* grad_w_hh;    /* acc */
-  float* grad_b_ih;    /* acc */
-  float* grad_b_hh;    /* acc */
-  void* workspace;     /* forward writes the gate/cell tape here when non-NULL; backward reads it */
+  const float* grad_h_out; /* [B][H] cotangent of h_out */
+  float* grad_gates;   /* out [T][B][4H]: d loss / d pre-activation gates per step (feeds the weight-gradient GEMMs) */
+  float* h_prev;       /* out [T][B][H]: hidden state entering each step (the other GEMM operand) */
+  void* workspace;     /* >= hode_lstm_workspace_bytes: packed weights (+ tape when save_tape) */
   size_t workspace_bytes;
 } hode_lstm_desc;
 

@@ -1,0 +1,78 @@
+"""HIP LSTM encoder kernel (fp32 MFMA, through the C ABI) vs the CPU oracle's explicit-gate LSTM.  GPU only.
+
+Tolerance: |h - h_oracle| <= 2e-5 (fp32 accumulation order differs: MFMA k-ordered fma chain vs BLAS blocking;
+gates use <= 2-ulp hardware exp/rcp)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.encoder import EncoderLSTMOracle
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _inputs(T, B, obs, seed, ad=1):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, B, obs, generator=gen)
+    a = torch.rand(T, B, ad, generator=gen) * (torch.rand(T, B, ad, generator=gen) < 0.1).float() if ad else None
+    m = (torch.rand(T, B, obs, generator=gen) < 0.5).float()
+    return x, a, m
+
+
+@pytest.mark.parametrize("obs,H,B,T", [(80, 160, 100, 12), (40, 80, 77, 9), (80, 160, 1000, 5), (24, 44, 50, 7), (80, 160, 16, 3),
+                                       (80, 160, 33, 1)])
+def test_final_state_matches_oracle(obs, H, B, T):
+    from hode.lstm import lstm_final_state
+    dev = _dev()
+    torch.manual_seed(obs + B)
+    enc = EncoderLSTMOracle(obs + 1, H, 12)
+    with torch.no_grad():
+        for p in enc.lstm.parameters():
+            p.mul_(1.5)
+    x, a, m = _inputs(T, B, obs, seed=B)
+    with torch.no_grad():
+        h_o, c_o = enc.final_hidden(x, a, m)
+    p = enc.lstm
+    h, c = lstm_final_state(x.to(dev), a.to(dev), m.to(dev), p.weight_ih_l0.to(dev), p.weight_hh_l0.to(dev),
+                            p.bias_ih_l0.to(dev), p.bias_hh_l0.to(dev), reverse=True)
+    assert (h.cpu() - h_o).abs().max().item() <= 2e-5, (h.cpu() - h_o).abs().max().item()
+    assert (c.cpu() - c_o).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("nt", [1, 2, 3, 4])
+def test_every_patient_tile_variant(nt, monkeypatch):
+    """The library picks the patient tile (16*NT) from the batch size; force each compiled variant on a ragged batch."""
+    from hode.lstm import lstm_final_state
+    dev = _dev()
+    monkeypatch.setenv("HODE_LSTM_NT", str(nt))
+    obs, H, B, T = 80, 160, 16 * nt * 3 + 5, 4
+    torch.manual_seed(nt)
+    enc = EncoderLSTMOracle(obs + 1, H, 12)
+    x, a, m = _inputs(T, B, obs, seed=nt)
+    with torch.no_grad():
+        h_o, c_o = enc.final_hidden(x, a, m)
+    p = enc.lstm
+    h, c = lstm_final_state(x.to(dev), a.to(dev), m.to(dev), p.weight_ih_l0.to(dev), p.weight_hh_l0.to(dev),
+                            p.bias_ih_l0.to(dev), p.bias_hh_l0.to(dev), reverse=True)
+    assert (h.cpu() - h_o).abs().max().item() <= 2e-5 and (c.cpu() - c_o).abs().max().item() <= 5e-5
+
+
+def test_forward_time_unmasked_variant():
+    """EncoderLSTMReal semantics: forward time order, no input masking, all inputs in one tensor."""
+    from hode.lstm import lstm_final_state
+    from oracle.encoder import lstm_cell
+    dev = _dev()
+    T, B, I, H = 6, 40, 37, 44
+    torch.manual_seed(5)
+    lstm = torch.nn.LSTM(I, H)
+    x = torch.randn(T, B, I)
+    with torch.no_grad():
+        out, (h_o, c_o) = lstm(x)
+    h, c = lstm_final_state(x.to(dev), None, None, lstm.weight_ih_l0.to(dev), lstm.weight_hh_l0.to(dev),
+                            lstm.bias_ih_l0.to(dev), lstm.bias_hh_l0.to(dev), reverse=False)
+    assert (h.cpu() - h_o[0]).abs().max().item() <= 2e-5

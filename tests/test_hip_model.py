@@ -1,0 +1,90 @@
+"""End-to-end parity of the host-side mirror on the GPU (encoder -> reparam off -> HIP solver -> readout -> loss ->
+backward) against the CPU oracle pipeline with identical weights and data.  GPU only."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import model
+from oracle import vi as ovi
+from oracle.encoder import EncoderLSTMOracle
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+@pytest.mark.parametrize("obs,D", [(40, 8), (80, 12)])
+def test_vi_loss_and_grads_match_cpu_oracle(method, obs, D):
+    from hode import synth
+    dev = _dev()
+    T, B, step = 20, 48, synth.STEP
+    torch.manual_seed(1)
+    enc = model.EncoderLSTM(obs + 1, obs * 2, D, device=dev)
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * step, step, method=method, device=dev)
+    vi = model.VariationalInference(enc, dec, elbo=False)
+    enc_o = EncoderLSTMOracle(obs + 1, obs * 2, D)
+    dec_o = ovi.DecoderOracle(obs, D, (T - 1) * step, step, method=method)
+    enc_o.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+    dec_o.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    sol = synth.solver_inputs(B, T, D, seed=3)
+    ob = synth.observation_inputs(B, T, obs, seed=3)
+    data = {"measurements": ob["measurements"], "actions": sol["actions"], "masks": ob["masks"]}
+    loss = vi.loss({k: v.to(dev) for k, v in data.items()})
+    loss.backward()
+    loss_o = ovi.vi_loss(enc_o, dec_o, data, elbo=False)
+    loss_o.backward()
+    tol_h, tol_g = (3e-5, 2e-3) if method == "rk4" else (2e-4, 5e-2)
+    assert abs(loss.item() - loss_o.item()) <= 2e-4 * abs(loss_o.item())
+    assert (vi.h_hat.detach().cpu() - odeint_h(dec_o, enc_o, data)).abs().max().item() <= tol_h * 10
+    for (n, p), (_, po) in zip(list(enc.named_parameters()) + list(dec.named_parameters()),
+                               list(enc_o.named_parameters()) + list(dec_o.named_parameters())):
+        if po.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        if float(po.grad.abs().max()) < 1e-12:
+            continue
+        assert _rel(p.grad, po.grad) <= tol_g, (n, _rel(p.grad, po.grad))
+
+
+def odeint_h(dec_o, enc_o, data):
+    with torch.no_grad():
+        mu, _ = enc_o(data["measurements"], data["actions"], data["masks"])
+        _, h = dec_o(mu, data["actions"])
+    return h
+
+
+def test_state_dict_roundtrip_and_training_step_changes_only_optimised_params(tmp_path):
+    """run_simulation.py optimises encoder + readout + ml_net only (reference :125-129); the 13 rate constants stay."""
+    from hode import synth
+    dev = _dev()
+    obs, D, T, B = 40, 8, 16, 32
+    torch.manual_seed(2)
+    enc = model.EncoderLSTM(obs + 1, obs * 2, D, device=dev)
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * synth.STEP, synth.STEP, method="rk4", device=dev)
+    vi = model.VariationalInference(enc, dec, prior_log_pdf=model.ExponentialPrior.log_density, mc_size=10)
+    params = list(enc.parameters()) + list(dec.output_function.parameters()) + list(dec.ode.ml_net.parameters())
+    opt = torch.optim.Adam(params, lr=0.01)
+    sol = synth.solver_inputs(B, T, D, seed=4)
+    ob = synth.observation_inputs(B, T, obs, seed=4)
+    data = {k: v.to(dev) for k, v in {"measurements": ob["measurements"], "actions": sol["actions"], "masks": ob["masks"]}.items()}
+    before = {k: v.clone() for k, v in dec.state_dict().items()}
+    l0 = vi.loss(data)
+    l0.backward()
+    opt.step()
+    after = dec.state_dict()
+    assert torch.equal(before["ode.kel"], after["ode.kel"]) and not torch.equal(before["ode.ml_net.0.weight"], after["ode.ml_net.0.weight"])
+    vi.save(str(tmp_path) + "/", 1, float(l0))
+    ck = torch.load(str(tmp_path) + "/" + vi.model_name)
+    assert set(ck) == {"itr", "encoder_state_dict", "decoder_state_dict", "best_loss"}
+    dec.load_state_dict(ck["decoder_state_dict"])
+    assert torch.isfinite(l0)
