@@ -240,6 +240,171 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- backward
+// Back-propagation through time of the recurrence.  Per step (walked in the reverse of the forward processing order)
+//   dh = carry (+ grad_h_out at the last processed step);  tc = tanh(c_t)
+//   d_o = dh tc o(1-o);  dc = carry_c + dh o (1 - tc^2);  d_i = dc g i(1-i);  d_f = dc c_prev f(1-f);  d_g = dc i (1-g^2)
+//   carry_c = dc f;  carry_h[u'] = sum_rho W_hh[rho][u'] dG[rho]     <- the only contraction: fp32 MFMA
+// The gate cotangents dG leave the kernel as grad_gates[T][B][4H] and the entering hidden state as h_prev[T][B][H]
+// (both row-major, written coalesced through an LDS transpose); the weight gradients are then three plain GEMMs
+// over K = T*B (dG^T x, dG^T h_prev, column sums), which the host wrapper hands to the BLAS library.
+//
+// MFMA mapping: out[u' (16 per tile) x patient] += W_hh^T[u' x rho] dG^T[rho x patient].  K (rho = gate rows) is
+// split over the waves: wave w contracts over the gate rows of ITS units, i.e. exactly the dG values it has just
+// produced.  With rho ordered (tile, gate, unit-in-tile) the B-operand fragment of k-quad (tile, gate) -- lane
+// (k = lane>>4, j = lane&15) -- IS the register that lane already holds from the element-wise step: no staging.
+// The four partial [H x BT] results are exchanged through LDS slabs and summed in a fixed order.
+struct LstmBwdArgs {
+  const float* __restrict__ tape;      // forward tape [T][nblk][4][TPW][NT][5][64]
+  const float* __restrict__ whp;       // packed W_hh^T fragments [4][TPW(tau)][TPW(mt)][64][4]
+  const float* __restrict__ grad_h_out;  // [B][H]
+  float* __restrict__ grad_gates;      // [T][B][4H]
+  float* __restrict__ h_prev;          // [T][B][H + AD]: hidden state entering the step, then the action columns
+  const float* __restrict__ a;         // [T][B][AD] or nullptr
+  int T, B, H, Hp, LD, reverse, AD;
+};
+
+__global__ void lstm_pack_hh_kernel(const float* __restrict__ w_hh, float* __restrict__ whp, int H, int TPW) {
+  const long long n = 4LL * TPW * TPW * 64 * 4;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    const int r = idx & 3;
+    const int l = (idx >> 2) & 63;
+    long long q = idx >> 8;
+    const int mt = (int)(q % TPW); q /= TPW;
+    const int tau = (int)(q % TPW);
+    const int w = (int)(q / TPW);
+    const int u = (w * TPW + tau) * 4 + (l >> 4);   // contracted unit (its gate r)
+    const int uo = 16 * mt + (l & 15);              // output unit
+    whp[idx] = (u < H && uo < H) ? w_hh[((size_t)r * H + u) * H + uo] : 0.f;
+  }
+}
+
+template <int NT, int TPW>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BT = 16 * NT;
+  constexpr int Hp = 16 * TPW;
+  constexpr int LDG = 4 * Hp + 4;   // row pitch of the dG transpose tile (pad: 2-way instead of 16-way conflicts)
+  constexpr int LDH = Hp + 4;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int g = l >> 4, pc = l & 15;
+  const int b0 = blockIdx.x * BT;
+  const int nvalid = min(BT, p.B - b0);
+  const int LD = p.LD;
+  float* dgt = lds;                      // [BT][LDG]   (time-shared with the partial slabs [4][Hp][LD])
+  float* slab = lds;
+  float* hT = lds + (size_t)BT * LDG;    // [BT][LDH]
+  const int H = p.H;
+
+  float carry_h[TPW][NT], carry_c[TPW][NT];
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int u = (w * TPW + tt) * 4 + g;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int b = 16 * c + pc;
+      carry_h[tt][c] = (u < H && b < nvalid) ? p.grad_h_out[(size_t)(b0 + b) * H + u] : 0.f;
+      carry_c[tt][c] = 0.f;
+    }
+  }
+  const size_t tape_step = (size_t)gridDim.x * 4 * TPW * NT * 5 * 64;
+  const size_t tape_blk = ((size_t)blockIdx.x * 4 + w) * TPW * NT * 5 * 64 + l;
+  const f32x4* whb = reinterpret_cast<const f32x4*>(p.whp) + (size_t)w * TPW * TPW * 64 + l;
+
+  for (int s = p.T - 1; s >= 0; --s) {
+    const int t = p.reverse ? p.T - 1 - s : s;
+    const int t_prev = p.reverse ? t + 1 : t - 1;   // time index processed one step earlier in the forward sweep
+    const float* tc = p.tape + (size_t)t * tape_step + tape_blk;
+    const float* tpv = (s > 0) ? p.tape + (size_t)t_prev * tape_step + tape_blk : nullptr;
+
+    f32x4 acc[TPW][NT];
+#pragma unroll
+    for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+      for (int c = 0; c < NT; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      const int u = (w * TPW + tt) * 4 + g;
+      f32x4 wf[TPW];
+#pragma unroll
+      for (int mt = 0; mt < TPW; ++mt) wf[mt] = whb[((size_t)tt * TPW + mt) * 64];
+      float dgr[NT][4];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const float* q5 = tc + (size_t)(tt * NT + c) * 5 * 64;
+        const float gi = q5[0], gf = q5[64], gg = q5[128], go = q5[192], cn = q5[256];
+        float c_prev = 0.f, h_prev = 0.f;
+        if (tpv) {
+          const float* p5 = tpv + (size_t)(tt * NT + c) * 5 * 64;
+          c_prev = p5[256];
+          h_prev = p5[192] * tanh_f32(c_prev);
+        }
+        const float tcn = tanh_f32(cn);
+        const float dh = carry_h[tt][c];
+        const float dc = __builtin_fmaf(dh * go, __builtin_fmaf(-tcn, tcn, 1.0f), carry_c[tt][c]);
+        dgr[c][0] = dc * gg * gi * (1.0f - gi);
+        dgr[c][1] = dc * c_prev * gf * (1.0f - gf);
+        dgr[c][2] = dc * gi * __builtin_fmaf(-gg, gg, 1.0f);
+        dgr[c][3] = dh * tcn * go * (1.0f - go);
+        carry_c[tt][c] = dc * gf;
+        const int b = 16 * c + pc;
+        if (u < Hp) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dgt[(size_t)b * LDG + r * Hp + u] = dgr[c][r];
+          hT[(size_t)b * LDH + u] = h_prev;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+          for (int c = 0; c < NT; ++c)
+            acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[mt][r], dgr[c][r], acc[mt][c], 0, 0, 0);
+    }
+    __syncthreads();
+    // coalesced row-major stores of this step's dG and h_prev tiles
+    {
+      float* gdst = p.grad_gates + ((size_t)t * p.B + b0) * 4 * H;
+      const int n4 = 4 * H;
+      for (int e = tid; e < nvalid * n4; e += 256) {
+        const int b = e / n4, col = e - b * n4;
+        const int r = col / H, u = col - r * H;
+        gdst[e] = dgt[(size_t)b * LDG + r * Hp + u];
+      }
+      const int HA = H + p.AD;
+      float* hdst = p.h_prev + ((size_t)t * p.B + b0) * HA;
+      for (int e = tid; e < nvalid * HA; e += 256) {
+        const int b = e / HA, u = e - b * HA;
+        hdst[e] = u < H ? hT[(size_t)b * LDH + u] : p.a[((size_t)t * p.B + b0 + b) * p.AD + (u - H)];
+      }
+    }
+    __syncthreads();
+    // exchange the K-split partial products: slab[w][u'][patient]
+#pragma unroll
+    for (int mt = 0; mt < TPW; ++mt)
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          slab[((size_t)w * Hp + 16 * mt + 4 * g + rr) * LD + 16 * c + pc] = acc[mt][c][rr];
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      const int u = (w * TPW + tt) * 4 + g;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const float* sp = slab + (size_t)u * LD + 16 * c + pc;
+        carry_h[tt][c] = ((sp[0] + sp[(size_t)Hp * LD]) + sp[(size_t)2 * Hp * LD]) + sp[(size_t)3 * Hp * LD];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace hode
 
 // ====================================================================================================== host
@@ -249,7 +414,7 @@ using hode::LstmArgs;
 
 struct LstmGeom {
   int Hp, TPW, NT, BT, nblk, Kq, KQ4, LD;
-  size_t wp_floats, bp_floats, tape_floats, lds_bytes;
+  size_t wp_floats, bp_floats, tape_floats, whp_floats, lds_bytes, lds_bwd_bytes;
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -266,17 +431,17 @@ int choose_nt(int B, bool bwd) {
   return best;
 }
 
-int lstm_geom(const hode_lstm_desc* d, LstmGeom* G) {
+int lstm_geom(const hode_lstm_desc* d, LstmGeom* G, bool bwd_compatible) {
   const int Hp = (d->hidden_dim + 15) / 16 * 16;
   G->Hp = Hp;
   G->TPW = Hp / 16;
   if (G->TPW != 3 && G->TPW != 5 && G->TPW != 10)
     return hode::fail(HODE_E_UNSUPPORTED, "lstm: hidden_dim %d (padded %d) has no compiled kernel (padded H in {48, 80, 160})",
                       d->hidden_dim, Hp);
-  G->NT = choose_nt(d->batch, false);
+  G->NT = choose_nt(d->batch, bwd_compatible);
   if (const char* env = getenv("HODE_LSTM_NT")) {  // tuning / test override of the patient tile (16 * NT)
     const int v = atoi(env);
-    if (v >= 1 && v <= 4) G->NT = v;
+    if (v >= 1 && v <= (bwd_compatible ? 3 : 4)) G->NT = v;
   }
   G->BT = 16 * G->NT;
   G->nblk = (d->batch + G->BT - 1) / G->BT;
@@ -295,6 +460,11 @@ int lstm_geom(const hode_lstm_desc* d, LstmGeom* G) {
   G->LD = G->BT + ((G->BT % 32 == 0) ? 16 : 0);
   G->tape_floats = (size_t)d->seq_len * G->nblk * 4 * G->TPW * G->NT * 5 * 64;
   G->lds_bytes = (size_t)2 * 4 * G->Kq * G->LD * sizeof(float);
+  G->whp_floats = (size_t)4 * G->TPW * G->TPW * 64 * 4;
+  {
+    const size_t tile = (size_t)G->BT * (4 * Hp + 4), slabs = (size_t)4 * Hp * G->LD;
+    G->lds_bwd_bytes = ((tile > slabs ? tile : slabs) + (size_t)G->BT * (Hp + 4)) * sizeof(float);
+  }
   if ((size_t)G->BT * d->obs_dim > 5120)
     return hode::fail(HODE_E_UNSUPPORTED, "lstm: obs_dim %d too wide for the staging registers", d->obs_dim);
   return 0;
@@ -344,18 +514,19 @@ int set_lds_attr_tpw(const LstmGeom& G) {
 
 }  // namespace
 
+// workspace: [packed Wcat | packed bias | packed W_hh^T (tape runs only) | tape (tape runs only)]
 extern "C" size_t hode_lstm_workspace_bytes(const hode_lstm_desc* d) {
   LstmGeom G;
-  if (!d || d->struct_size != sizeof(hode_lstm_desc) || lstm_geom(d, &G)) return 0;
+  if (!d || d->struct_size != sizeof(hode_lstm_desc) || lstm_geom(d, &G, d->save_tape != 0)) return 0;
   size_t n = align256(G.wp_floats * 4) + align256(G.bp_floats * 4);
-  if (d->save_tape) n += align256(G.tape_floats * 4);
+  if (d->save_tape) n += align256(G.whp_floats * 4) + align256(G.tape_floats * 4);
   return n;
 }
 
 extern "C" int hode_lstm_fwd(const hode_lstm_desc* d, void* stream) {
   if (int e = check_lstm(d)) return e;
   LstmGeom G;
-  if (int e = lstm_geom(d, &G)) return e;
+  if (int e = lstm_geom(d, &G, d->save_tape != 0)) return e;
   const size_t need = hode_lstm_workspace_bytes(d);
   if (!d->workspace || d->workspace_bytes < need)
     return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, need);
@@ -363,7 +534,7 @@ extern "C" int hode_lstm_fwd(const hode_lstm_desc* d, void* stream) {
   char* ws = (char*)d->workspace;
   float* wp = (float*)ws;
   float* bp = (float*)(ws + align256(G.wp_floats * 4));
-  float* tape = d->save_tape ? (float*)(ws + align256(G.wp_floats * 4) + align256(G.bp_floats * 4)) : nullptr;
+  float* tape = d->save_tape ? (float*)(ws + align256(G.wp_floats * 4) + align256(G.bp_floats * 4) + align256(G.whp_floats * 4)) : nullptr;
   hipLaunchKernelGGL(hode::lstm_pack_kernel, dim3(256), dim3(256), 0, s, d->w_ih, d->w_hh, d->b_ih, d->b_hh, wp, bp,
                      d->input_dim, d->hidden_dim, G.TPW, G.KQ4);
   if (int e = hode::hip_fail(hipGetLastError(), "lstm_pack launch")) return e;
@@ -381,6 +552,60 @@ extern "C" int hode_lstm_fwd(const hode_lstm_desc* d, void* stream) {
   return e;
 }
 
-extern "C" int hode_lstm_bwd(const hode_lstm_desc*, void*) {
-  return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_bwd: not built yet");
+namespace {
+
+template <int NT, int TPW>
+int launch_bwd_one(const LstmGeom& G, const hode::LstmBwdArgs& a, hipStream_t s) {
+  if (int e = hode::hip_fail(hipFuncSetAttribute((const void*)hode::lstm_bwd_kernel<NT, TPW>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G.lds_bwd_bytes),
+                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
+    return e;
+  hipLaunchKernelGGL((hode::lstm_bwd_kernel<NT, TPW>), dim3(G.nblk), dim3(256), G.lds_bwd_bytes, s, a);
+  return hode::hip_fail(hipGetLastError(), "lstm_bwd launch");
+}
+
+template <int NT>
+int launch_bwd_tpw(const LstmGeom& G, const hode::LstmBwdArgs& a, hipStream_t s) {
+  switch (G.TPW) {
+    case 3: return launch_bwd_one<NT, 3>(G, a, s);
+    case 5: return launch_bwd_one<NT, 5>(G, a, s);
+    case 10: return launch_bwd_one<NT, 10>(G, a, s);
+  }
+  return hode::fail(HODE_E_UNSUPPORTED, "lstm_bwd: no kernel for TPW %d", G.TPW);
+}
+
+}  // namespace
+
+// Backward of hode_lstm_fwd(save_tape = 1) with the SAME descriptor sizes and workspace: fills grad_gates[T][B][4H]
+// and h_prev[T][B][H + A] (hidden state entering each step, then the A action columns); the caller forms
+// grad_w_ih[:, :obs] = grad_gates^T (x*mask), [grad_w_hh | grad_w_ih[:, obs:]] = grad_gates^T h_prev and
+// grad_b_ih = grad_b_hh = column sums of grad_gates (plain GEMMs over K = T*B).
+extern "C" int hode_lstm_bwd(const hode_lstm_desc* d, void* stream) {
+  if (int e = check_lstm(d)) return e;
+  if (!d->save_tape) return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_bwd needs the tape of a forward run with save_tape = 1");
+  if (!d->grad_h_out || !d->grad_gates || !d->h_prev)
+    return hode::fail(HODE_E_NULL, "grad_h_out / grad_gates / h_prev must be non-NULL");
+  LstmGeom G;
+  if (int e = lstm_geom(d, &G, true)) return e;
+  const size_t need = hode_lstm_workspace_bytes(d);
+  if (!d->workspace || d->workspace_bytes < need)
+    return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, need);
+  if (G.lds_bwd_bytes > 160 * 1024)
+    return hode::fail(HODE_E_UNSUPPORTED, "lstm_bwd: tile needs %zu B of LDS (> 160 KiB)", G.lds_bwd_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)d->workspace;
+  float* whp = (float*)(ws + align256(G.wp_floats * 4) + align256(G.bp_floats * 4));
+  const float* tape = (const float*)((char*)whp + align256(G.whp_floats * 4));
+  hipLaunchKernelGGL(hode::lstm_pack_hh_kernel, dim3(128), dim3(256), 0, s, d->w_hh, whp, d->hidden_dim, G.TPW);
+  if (int e = hode::hip_fail(hipGetLastError(), "lstm_pack_hh launch")) return e;
+  hode::LstmBwdArgs a{};
+  a.tape = tape; a.whp = whp; a.grad_h_out = d->grad_h_out; a.grad_gates = d->grad_gates; a.h_prev = d->h_prev;
+  a.T = d->seq_len; a.B = d->batch; a.H = d->hidden_dim; a.Hp = G.Hp; a.LD = G.LD; a.reverse = d->reverse;
+  a.a = d->a; a.AD = d->input_dim - d->obs_dim;
+  switch (G.NT) {
+    case 1: return launch_bwd_tpw<1>(G, a, s);
+    case 2: return launch_bwd_tpw<2>(G, a, s);
+    case 3: return launch_bwd_tpw<3>(G, a, s);
+  }
+  return hode::fail(HODE_E_UNSUPPORTED, "lstm_bwd: NT %d", G.NT);
 }

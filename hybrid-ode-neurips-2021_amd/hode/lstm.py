@@ -45,3 +45,77 @@ def lstm_final_state(x, a, mask, w_ih, w_hh, b_ih, b_hh, reverse=True):
     with torch.cuda.device(x.device):
         L.check(lib.hode_lstm_fwd(d, _stream()), "hode_lstm_fwd")
     return h, c
+
+
+def _splitk_tn(lhs, rhs):
+    """lhs^T @ rhs for tall operands (K x M, K x N with K ~ 1e6, M, N ~ 1e2): the BLAS heuristics pick a kernel without
+    split-K for this shape (2.4-3.5 ms measured); batching K into P slices and summing runs 2x faster (tools/gemm_probe.py)."""
+    K = lhs.shape[0]
+    P = 1
+    for cand in range(256, 1, -1):
+        if K % cand == 0 and K // cand >= 1024:
+            P = cand
+            break
+    if P == 1:
+        return lhs.t() @ rhs
+    return torch.bmm(lhs.view(P, K // P, -1).transpose(1, 2), rhs.view(P, K // P, -1)).sum(0)
+
+
+class _LstmEncode(torch.autograd.Function):
+    """h_final = LSTM(window); backward = BPTT kernel + three BLAS GEMMs over K = T*B for the weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, a, mask, w_ih, w_hh, b_ih, b_hh, reverse):
+        _require_gpu(x, w_ih)
+        lib = L.lib()
+        xc, ac, mc = _f32c(x), (None if a is None else _f32c(a)), (None if mask is None else _f32c(mask))
+        wi, wh, bi, bh = _f32c(w_ih), _f32c(w_hh), _f32c(b_ih), _f32c(b_hh)
+        B, H = xc.shape[1], wh.shape[1]
+        h = torch.empty((B, H), device=x.device, dtype=torch.float32)
+        c = torch.empty((B, H), device=x.device, dtype=torch.float32)
+        d = _desc(xc, ac, mc, wi, wh, bi, bh, reverse, True)
+        d.h_out, d.c_out = h.data_ptr(), c.data_ptr()
+        nbytes = lib.hode_lstm_workspace_bytes(d)
+        if nbytes == 0:
+            L.check(lib.hode_lstm_fwd(d, _stream()), "hode_lstm_fwd")
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        with torch.cuda.device(x.device):
+            L.check(lib.hode_lstm_fwd(d, _stream()), "hode_lstm_fwd")
+        ctx.save_for_backward(xc, ac if ac is not None else xc, mc if mc is not None else xc, wi, wh, bi, bh, ws)
+        ctx.flags = (ac is not None, mc is not None, bool(reverse))
+        return h
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        xc, ac, mc, wi, wh, bi, bh, ws = ctx.saved_tensors
+        has_a, has_m, reverse = ctx.flags
+        ac = ac if has_a else None
+        mc = mc if has_m else None
+        lib = L.lib()
+        T, B, obs = xc.shape
+        H = wh.shape[1]
+        gh = grad_h.to(torch.float32).contiguous()
+        dgates = torch.empty((T, B, 4 * H), device=xc.device, dtype=torch.float32)
+        ad = 0 if ac is None else ac.shape[-1]
+        hprev = torch.empty((T, B, H + ad), device=xc.device, dtype=torch.float32)
+        d = _desc(xc, ac, mc, wi, wh, bi, bh, reverse, True)
+        h_dummy = torch.empty(1, device=xc.device)
+        d.h_out, d.c_out = h_dummy.data_ptr(), h_dummy.data_ptr()  # unused by the backward, must be non-NULL
+        d.grad_h_out, d.grad_gates, d.h_prev = gh.data_ptr(), dgates.data_ptr(), hprev.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        with torch.cuda.device(xc.device):
+            L.check(lib.hode_lstm_bwd(d, _stream()), "hode_lstm_bwd")
+        dg2 = dgates.view(T * B, 4 * H)
+        xm = xc * mc if mc is not None else xc
+        g_wih_x = _splitk_tn(dg2, xm.view(T * B, obs))
+        g_ha = _splitk_tn(dg2, hprev.view(T * B, H + ad))     # [grad_w_hh | action columns of grad_w_ih]
+        g_whh = g_ha[:, :H].contiguous()
+        g_wih = g_wih_x if ad == 0 else torch.cat([g_wih_x, g_ha[:, H:]], dim=1)
+        g_b = dg2.sum(dim=0)
+        return None, None, None, g_wih, g_whh, g_b, g_b.clone(), None
+
+
+def lstm_encode(x, a, mask, w_ih, w_hh, b_ih, b_hh, reverse=True):
+    """Differentiable (w.r.t. the four LSTM parameters) final hidden state (B, H) of the masked window LSTM."""
+    return _LstmEncode.apply(x, a, mask, w_ih, w_hh, b_ih, b_hh, bool(reverse))

@@ -75,12 +75,19 @@ class EncoderLSTM(nn.Module, GaussianReparam):
         self.log_var = nn.Linear(hidden_dim, output_dim).to(self.device)
 
     def final_hidden(self, x, a, mask):
-        """h after walking t = T-1 .. 0 on cat(x,a)*cat(mask,1).  One fused sequence call on the time-flipped,
-        pre-masked input replaces the reference's T single-step ``nn.LSTM`` calls (same arithmetic)."""
+        """h after walking t = T-1 .. 0 on cat(x,a)*cat(mask,1) (reference model.py:415-422).
+
+        HIP tensors: the fp32-MFMA window kernel (``hode.lstm``: mask/concat fused, h and c stay on chip, BPTT kernel
+        for the backward).  CPU tensors (host-logic tests): one ``nn.LSTM`` sequence call on the flipped, pre-masked
+        input -- the reference's own operator, same arithmetic as its T single-step calls."""
         if x.dim() == 3 and x.shape[1] == 1:
             raise RuntimeError("EncoderLSTM: batch size 1 is not supported (the reference's x.squeeze() drops the batch axis)")
+        p = self.lstm
+        if x.is_cuda:
+            from hode.lstm import lstm_encode
+            return lstm_encode(x, a, mask, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, reverse=True)
         seq = torch.cat([x * mask, a], dim=-1).flip(0)
-        _, (h, _) = self.lstm(seq)
+        _, (h, _) = p(seq)
         return h[0]
 
     def forward(self, x, a, mask):

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "hybrid-ode-neurips-2021_amd")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import test_hip_dopri5 as T
 dev = torch.device("cuda:0")

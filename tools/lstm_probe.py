@@ -1,7 +1,7 @@
 """Forward time of the MFMA LSTM encoder vs nn.LSTM (MIOpen).  nn.LSTM is skipped when T*B*4H exceeds int32
 (MIOpen faults there: observed at T=100, B=40000, H=160)."""
 import sys, os, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "hybrid-ode-neurips-2021_amd"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
 import torch
 from hode.lstm import lstm_final_state
 dev = torch.device("cuda:0")

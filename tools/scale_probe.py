@@ -1,5 +1,5 @@
 import sys, os, json
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "hybrid-ode-neurips-2021_amd"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
 import torch, bench
 for n in (2500, 5000, 10000, 20000, 40000, 80000, 160000):
     for lanes in (4, 1):

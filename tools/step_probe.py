@@ -1,6 +1,6 @@
 """Timing of the full loss step of the mirror model on one GPU: encoder (nn.LSTM / MIOpen) vs solver vs readout+loss."""
 import sys, os, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "hybrid-ode-neurips-2021_amd"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
 import torch, model
 from hode import synth
 dev = torch.device("cuda:0")
@@ -22,7 +22,7 @@ print("full loss+backward: %.2f ms" % timeit(full))
 def enc_only():
     for p in enc.parameters(): p.grad = None
     mu, lv = enc(data["measurements"], data["actions"], data["masks"]); (mu.sum() + lv.sum()).backward()
-print("encoder fwd+bwd (nn.LSTM): %.2f ms" % timeit(enc_only))
+print("encoder fwd+bwd (hode MFMA LSTM): %.2f ms" % timeit(enc_only))
 with torch.no_grad():
     print("encoder fwd only: %.2f ms" % timeit(lambda: enc(data["measurements"], data["actions"], data["masks"])))
 z = torch.rand(N, D, device=dev) * 0.01
