@@ -105,6 +105,50 @@ def cpu_baseline(inp, wb, n_sample=2000, reps=3):
                       % (n_sample, N_PER_GPU, T, D, reps, med)}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant (backward) kernel from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc_summary.json, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); None if absent."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            if "rk_bwd_kernel<12" in k and "hbm_bytes_per_launch" in v:
+                best = {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
+    return best
+
+
+def full_step_ms(dev, iters=5):
+    """Extra (not the headline): one full training step of the mirror model at the same shape -- MFMA LSTM encoder
+    (obs 80 -> H 160), HIP solver, readout, masked SSE + MC-KL, backward through everything."""
+    import model
+    from hode import synth
+    obs = 80
+    torch.manual_seed(synth.SEED)
+    enc = model.EncoderLSTM(obs + 1, obs * 2, D, device=dev)
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * synth.STEP, synth.STEP, method="rk4", device=dev)
+    vi = model.VariationalInference(enc, dec, prior_log_pdf=model.ExponentialPrior.log_density)
+    sol = synth.solver_inputs(N_PER_GPU, T, D)
+    ob = synth.observation_inputs(N_PER_GPU, T, obs)
+    data = {k: v.to(dev) for k, v in {"measurements": ob["measurements"], "actions": sol["actions"], "masks": ob["masks"]}.items()}
+
+    def step():
+        for p in vi.parameters():
+            p.grad = None
+        vi.loss(data).backward()
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
 def kernel_times(plan, iters=20):
     """Average duration of the forward and backward launches, HIP events on the launch stream (torch's current)."""
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
@@ -129,6 +173,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--lanes", type=int, default=0, help="force lanes per patient (1|4), 0 = library default")
     ap.add_argument("--no-theta-grad", action="store_true", help="skip the 13 expert-constant gradients")
+    ap.add_argument("--full-step", action="store_true", help="also time one full training step (encoder + loss) as an extra field")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,6 +257,14 @@ def main():
                                  "achieved": plan.fwd_bytes / fwd_s / 1e9},
                          "step_frac": (plan.fwd_bytes + plan.bwd_bytes) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        tr = pmc_traffic()
+        if tr is not None:
+            out["roofline"]["traffic"] = tr["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
+        if args.full_step:
+            ms_full = full_step_ms(dev)
+            out["full_training_step"] = {"ms": ms_full, "trajectories_per_s": N_PER_GPU / ms_full * 1e3,
+                                         "what": "EncoderLSTM(81->160, MFMA) + rk4 solve + readout + masked SSE + MC-KL, fwd+bwd"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(inp, wb)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
