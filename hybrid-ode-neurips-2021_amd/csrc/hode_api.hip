@@ -141,6 +141,8 @@ extern "C" const char* hode_last_error_string(void) { return hode::g_err; }
 
 extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
   if (!d || d->struct_size != sizeof(hode_solve_desc)) return 0;
+  if (d->rhs_kind == HODE_RHS_NEURAL && (which == HODE_WS_RK_FWD || which == HODE_WS_RK_BWD))
+    return hode::neural_workspace_bytes(d, which == HODE_WS_RK_BWD);
   switch (which) {
     case HODE_WS_RK_FWD: return 0;
     case HODE_WS_RK_BWD: return (size_t)n_waves_for(d->batch, choose_lpp(d)) * n_partials(d) * sizeof(float);
@@ -151,11 +153,15 @@ extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
 }
 
 extern "C" int hode_rk_fwd(const hode_solve_desc* d, void* stream) {
+  if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_NEURAL)
+    return hode::neural_rk(d, false, (hipStream_t)stream);
   if (int e = check_rk(d, false)) return e;
   return dispatch_dim(d, false, (hipStream_t)stream);
 }
 
 extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
+  if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_NEURAL)
+    return hode::neural_rk(d, true, (hipStream_t)stream);
   if (int e = check_rk(d, true)) return e;
   const size_t need = hode_workspace_bytes(d, HODE_WS_RK_BWD);
   if (!d->workspace || d->workspace_bytes < need)

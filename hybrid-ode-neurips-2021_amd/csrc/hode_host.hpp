@@ -47,6 +47,10 @@ int dp_dispatch_d6(const DpLaunch&, const DpArgs&, hipStream_t);
 int dp_dispatch_d8(const DpLaunch&, const DpArgs&, hipStream_t);
 int dp_dispatch_d12(const DpLaunch&, const DpArgs&, hipStream_t);
 
+// neural rhs (hode_neural.hip)
+size_t neural_workspace_bytes(const hode_solve_desc* d, bool bwd);
+int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
+
 // shared host helpers (hode_api.hip)
 int hip_fail(hipError_t e, const char* what);
 int n_waves_for(int B, int lpp);

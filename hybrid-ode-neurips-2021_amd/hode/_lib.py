@@ -68,6 +68,7 @@ EXPORTS = (
     ("hode_last_error_string", C.c_char_p, ()),
     ("hode_workspace_bytes", C.c_size_t, (C.POINTER(SolveDesc), C.c_int)),
     ("hode_lstm_workspace_bytes", C.c_size_t, (C.POINTER(LstmDesc),)),
+    ("hode_neural_tape_offsets", C.c_int, (C.POINTER(SolveDesc), C.POINTER(C.c_size_t))),
     ("hode_rk_fwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
     ("hode_rk_bwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
     ("hode_dopri5_fwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),

@@ -190,6 +190,42 @@ class RocheODE(nn.Module):
                                 check_finite=self.check_finite)
 
 
+class NeuralODE(nn.Module):
+    """Pure neural rhs ``tanh(W2 tanh(W1 [y, Dose(t)] + b1) + b2)`` with an impulse dose (model.py:969-1026)."""
+
+    def __init__(self, latent_dim, action_dim, t_max, step_size, device=None, dtype=DTYPE):
+        super().__init__()
+        assert action_dim == 1
+        self.action_dim = action_dim
+        self.latent_dim = int(latent_dim)
+        self.expert_dim = 4
+        self.ml_dim = self.latent_dim
+        self.device = get_device() if device is None else device
+        self.t_max, self.step_size = t_max, step_size
+        self.kel = nn.Parameter(torch.tensor(sim_config.RochConfig().kel, device=self.device, dtype=dtype))  # unused by forward
+        d = self.latent_dim
+        self.ml_net = nn.Sequential(nn.Linear(d + 1, d * 10), nn.Tanh(), nn.Linear(d * 10, d), nn.Tanh()).to(self.device)
+        self.times = None
+        self.dosage = None
+
+    set_action = RocheODE.set_action
+
+    def dose_at_time(self, t):
+        return self.dosage * torch.sum(self.times == t, dim=-1)
+
+    def forward(self, t, y):
+        return self.ml_net(torch.cat([y, self.dose_at_time(t)[:, None]], dim=-1))
+
+    def hode_solve(self, y0, t, rtol, atol, method, options):
+        if self.times is None:
+            raise RuntimeError("NeuralODE: call set_action(a) before integrating")
+        from hode import neural
+        if options.pop("step_size", None) is not None:
+            raise hode.HodeError("hode: options['step_size'] is not supported yet")
+        return neural.neural_solve(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight, self.ml_net[2].bias,
+                                   t, self.dosage, self.times, method=method, perturb=bool(options.pop("perturb", False)))
+
+
 class RocheExpertDecoder(nn.Module):
     """z0 -> latent trajectory h (T,B,D) on the observation grid -> linear readout x_hat (model.py:1030-1121)."""
 
@@ -212,7 +248,7 @@ class RocheExpertDecoder(nn.Module):
         if roche:
             self.ode = RocheODE(latent_dim, action_dim, t_max, step_size, ablate=ablate, device=self.device)
         else:
-            raise hode.HodeError("RocheExpertDecoder(roche=False): the NeuralODE rhs kernel is not built yet")
+            self.ode = NeuralODE(latent_dim, action_dim, t_max, step_size, self.device)
         self._odeint = hode.odeint  # tests swap in the CPU oracle here; the product path never does
 
     def forward(self, init, a):

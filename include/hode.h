@@ -163,6 +163,12 @@ typedef struct hode_lstm_desc {
 int hode_version(void);
 const char* hode_last_error_string(void);
 
+/* HODE_RHS_NEURAL backward: hode_rk_bwd fills grad_y0 and writes, per (step, stage) instance, the four operands of
+ * the weight-gradient GEMMs patient-minor into the workspace: a1t[inst][10D][B], u1t[inst][10D][B], yet[inst][D+1][B],
+ * u2t[inst][D][B] (inst = (T-1) * stages).  This returns their byte offsets; the caller contracts them:
+ * grad_w1 = sum_inst u1t yet^T, grad_b1 = sum u1t, grad_w2 = sum_inst u2t a1t^T, grad_b2 = sum u2t. */
+int hode_neural_tape_offsets(const hode_solve_desc* desc, size_t* out4);
+
 /* bytes of device scratch the given entry point needs for this descriptor (0 if none) */
 size_t hode_workspace_bytes(const hode_solve_desc* desc, int which);
 size_t hode_lstm_workspace_bytes(const hode_lstm_desc* desc);
