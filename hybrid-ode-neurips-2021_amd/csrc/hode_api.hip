@@ -143,6 +143,8 @@ extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
   if (!d || d->struct_size != sizeof(hode_solve_desc)) return 0;
   if (d->rhs_kind == HODE_RHS_NEURAL && (which == HODE_WS_RK_FWD || which == HODE_WS_RK_BWD))
     return hode::neural_workspace_bytes(d, which == HODE_WS_RK_BWD);
+  if (d->rhs_kind == HODE_RHS_ROCHE_REAL && (which == HODE_WS_RK_FWD || which == HODE_WS_RK_BWD))
+    return hode::real_workspace_bytes(d, which == HODE_WS_RK_BWD);
   switch (which) {
     case HODE_WS_RK_FWD: return 0;
     case HODE_WS_RK_BWD: return (size_t)n_waves_for(d->batch, choose_lpp(d)) * n_partials(d) * sizeof(float);
@@ -155,6 +157,8 @@ extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
 extern "C" int hode_rk_fwd(const hode_solve_desc* d, void* stream) {
   if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_NEURAL)
     return hode::neural_rk(d, false, (hipStream_t)stream);
+  if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_ROCHE_REAL)
+    return hode::real_rk(d, false, (hipStream_t)stream);
   if (int e = check_rk(d, false)) return e;
   return dispatch_dim(d, false, (hipStream_t)stream);
 }
@@ -162,6 +166,8 @@ extern "C" int hode_rk_fwd(const hode_solve_desc* d, void* stream) {
 extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
   if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_NEURAL)
     return hode::neural_rk(d, true, (hipStream_t)stream);
+  if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_ROCHE_REAL)
+    return hode::real_rk(d, true, (hipStream_t)stream);
   if (int e = check_rk(d, true)) return e;
   const size_t need = hode_workspace_bytes(d, HODE_WS_RK_BWD);
   if (!d->workspace || d->workspace_bytes < need)

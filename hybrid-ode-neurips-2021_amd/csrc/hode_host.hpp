@@ -51,6 +51,10 @@ int dp_dispatch_d12(const DpLaunch&, const DpArgs&, hipStream_t);
 size_t neural_workspace_bytes(const hode_solve_desc* d, bool bwd);
 int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
 
+// real-data rhs (hode_real.hip)
+size_t real_workspace_bytes(const hode_solve_desc* d, bool bwd);
+int real_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
+
 // shared host helpers (hode_api.hip)
 int hip_fail(hipError_t e, const char* what);
 int n_waves_for(int B, int lpp);

@@ -11,7 +11,9 @@ latent ODE is integrated by the gfx950 kernels of ``libhode.so`` (``hode.odeint`
     GaussianReparam / ExponentialPrior / StandardNormalPrior  model.py:18-45
     VariationalInference model.py:1124-1214    VariationalInference
 
-Out of scope: flow encoders, baselines, real-data variants (added with config 5).
+    EncoderLSTMReal / RocheODEReal / DecoderReal / VariationalInferenceReal  model.py:180-242, 570-657, 772-862, 1217-1261
+
+Out of scope: flow encoders, baselines (NeuralODEReal*, DecoderRealBenchmark).
 """
 
 from __future__ import annotations
@@ -258,6 +260,139 @@ class RocheExpertDecoder(nn.Module):
         return self.output_function(h), h
 
 
+class EncoderLSTMReal(nn.Module, GaussianReparam):
+    """Real-data encoder (model.py:180-242): LSTM over cat(x, a_in, t/max(mask)) with NO input masking, two-layer tanh
+    heads; ``reverse`` flips the window first, ``output_all`` is not used on the hot path (run_real.py passes False)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, output_all=False, reverse=True, normalize=True, device=None):
+        super().__init__()
+        self.device = get_device() if device is None else device
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.normalize = normalize
+        self.model_name = "LSTMReal"
+        self.lstm = nn.LSTM(input_dim, hidden_dim).to(self.device)
+        self.lin = nn.Sequential(nn.Linear(hidden_dim, hidden_dim + 1), nn.Tanh(), nn.Linear(hidden_dim + 1, output_dim), nn.Tanh()).to(self.device)
+        self.log_var = nn.Sequential(nn.Linear(hidden_dim, hidden_dim + 1), nn.Tanh(), nn.Linear(hidden_dim + 1, output_dim), nn.Tanh()).to(self.device)
+        self.reverse = reverse
+        self.output_all = output_all
+
+    def forward(self, x, a, m):
+        if self.output_all:
+            raise hode.HodeError("EncoderLSTMReal(output_all=True) is outside the accelerated path")
+        if self.reverse:
+            x, a, m = torch.flip(x, [0]), torch.flip(a, [0]), torch.flip(m, [0])
+        T, B = m.shape[0], m.shape[1]
+        tt = (torch.arange(T, device=x.device, dtype=x.dtype) / m.max()).view(T, 1, 1).expand(T, B, 1)
+        x_in = torch.cat([x, a, tt], dim=-1)
+        p = self.lstm
+        if x_in.is_cuda:
+            from hode.lstm import lstm_encode
+            out = lstm_encode(x_in, None, None, p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, reverse=False)
+        else:
+            out = p(x_in)[1][0][0]
+        return self.lin(out), self.log_var(out)
+
+
+class RocheODEReal(nn.Module):
+    """Real-data hybrid rhs: two small MLPs for x1, x2, expert x3 / Dose2, GRU-ODE block on the rest (model.py:570-657)."""
+
+    def __init__(self, latent_dim, action_dim, static_dim, hidden_dim, t_max, step_size, device=None, dtype=DTYPE):
+        super().__init__()
+        self.action_dim, self.latent_dim = int(action_dim), int(latent_dim)
+        self.static_dim, self.hidden_dim = int(static_dim), int(hidden_dim)
+        self.dosage = None
+        self.times = None
+        self.device = get_device() if device is None else device
+        self.t_max, self.step_size = t_max, step_size
+        h = self.hidden_dim
+        self.dx1_net = nn.Sequential(nn.Linear(3, h), nn.Tanh(), nn.Linear(h, 1), nn.Tanh())
+        self.dx2_net = nn.Sequential(nn.Linear(2, h), nn.Tanh(), nn.Linear(h, 1), nn.Tanh())
+        self.expert_dim = 4
+        self.expert_only = self.latent_dim == self.expert_dim
+        if not self.expert_only:
+            m = self.latent_dim - self.expert_dim
+            self.lin_hh = nn.Linear(m, m, bias=False)
+            self.lin_hz = nn.Linear(m, m, bias=False)
+            self.lin_hr = nn.Linear(m, m, bias=False)
+        self.k_immunity = nn.Parameter(torch.tensor(1, device=self.device, dtype=dtype))
+        self.kel = nn.Parameter(torch.tensor(0.2, device=self.device, dtype=dtype))
+        self.kel2 = nn.Parameter(torch.tensor(0.2, device=self.device, dtype=dtype))
+        self.to(self.device)  # the reference leaves the sub-networks on the default device; everything lives on one here
+
+    def set_action_static(self, action, static):
+        self.dosage = action
+        self.times = torch.cumsum(torch.ones_like(action), dim=0)
+
+    def dose_at_time(self, t):
+        on = t >= self.times
+        return torch.sum(self.dosage * torch.exp(self.kel * (self.times - t) * on) * on, dim=(0, 2))
+
+    def forward(self, t, y):
+        dose = self.dose_at_time(t)
+        cols = [self.dx1_net(y[:, :3]), self.dx2_net(y[:, :2]), (y[:, 1] * self.k_immunity)[..., None],
+                (self.kel * dose - self.kel2 * y[:, 3])[..., None]]
+        if not self.expert_only:
+            hv = y[..., 4:]
+            r = torch.sigmoid(self.lin_hr(hv))
+            z = torch.sigmoid(self.lin_hz(hv))
+            u = torch.tanh(self.lin_hh(r * hv))
+            cols.append((1 - z) * (u - hv))
+        return torch.cat(cols, dim=-1)
+
+    def flat_weights(self):
+        ps = [self.dx1_net[0].weight, self.dx1_net[0].bias, self.dx1_net[2].weight, self.dx1_net[2].bias,
+              self.dx2_net[0].weight, self.dx2_net[0].bias, self.dx2_net[2].weight, self.dx2_net[2].bias]
+        if not self.expert_only:
+            ps += [self.lin_hh.weight, self.lin_hz.weight, self.lin_hr.weight]
+        return torch.cat([p.reshape(-1) for p in ps])
+
+    def hode_solve(self, y0, t, rtol, atol, method, options):
+        if self.dosage is None:
+            raise RuntimeError("RocheODEReal: call set_action_static(a, s) before integrating")
+        from hode import real
+        step_size = options.pop("step_size", None)
+        if step_size is not None and t.numel() > 1:
+            # torchdiffeq builds its own grid t0 + k*step_size; supported when that grid IS the output grid
+            if not torch.allclose(t[1:] - t[:-1], torch.full_like(t[1:], float(step_size))):
+                raise hode.HodeError("hode: options['step_size'] different from the output spacing (sub-stepping) is not supported yet")
+        options.pop("step_t", None)  # ignored by fixed-grid solvers (torchdiffeq only warns)
+        theta = torch.stack([self.k_immunity, self.kel, self.kel2])
+        return real.real_solve(y0, theta, self.flat_weights(), t, self.dosage[..., 0], self.hidden_dim, method=method,
+                               perturb=bool(options.pop("perturb", False)))
+
+
+class DecoderReal(nn.Module):
+    """z0 -> h over t = t0-1 .. t_max-1 -> MLP readout, first output row dropped (model.py:772-862; hybrid ode_type)."""
+
+    def __init__(self, obs_dim, latent_dim, action_dim, static_dim, hidden_dim, t_max, step_size, t0=0, method="dopri5",
+                 ode_step_size=None, ode_type="neural", device=None, dtype=DTYPE):
+        super().__init__()
+        self.time_dim = int(t_max / step_size)
+        self.obs_dim, self.latent_dim, self.action_dim = obs_dim, latent_dim, action_dim
+        self.t_max, self.t0 = t_max, t0
+        self.static_dim, self.hidden_dim = int(static_dim), int(hidden_dim)
+        self.model_name = "DecoderReal_" + ode_type
+        self.device = get_device() if device is None else device
+        self.output_function = nn.Sequential(nn.Linear(latent_dim, latent_dim + 1, bias=True), nn.ELU(),
+                                             nn.Linear(latent_dim + 1, obs_dim, bias=True)).to(self.device)
+        if ode_type in ("neural", "2nd"):
+            raise hode.HodeError("DecoderReal(ode_type=%r): NeuralODEReal baselines are outside the accelerated path" % ode_type)
+        self.ode = RocheODEReal(latent_dim, action_dim, static_dim, hidden_dim, t_max, step_size, self.device)
+        self.t = torch.arange(t0 - 1, t_max, step_size, device=self.device, dtype=dtype)
+        self.options = {"step_t": self.t, "step_size": ode_step_size, "perturb": True}
+        self.rtol, self.atol = 1e-7, 1e-8
+        self.method = method
+        self.step_size = ode_step_size
+        self._odeint = hode.odeint
+
+    def forward(self, init, a, s):
+        self.ode.set_action_static(a, s)
+        if init.dim() != 2:
+            raise hode.HodeError("DecoderReal: per-step initial states (3-D init) are outside the accelerated path")
+        h = self._odeint(self.ode, init, self.t, method=self.method, options=dict(self.options), rtol=self.rtol, atol=self.atol)
+        return self.output_function(h)[1:], h
+
+
 class VariationalInference:
     """Negative ELBO: masked SSE likelihood + KL (analytic vs N(0,1), or Monte-Carlo vs a given prior) (model.py:1124-1214)."""
 
@@ -306,3 +441,33 @@ class VariationalInference:
         z = torch.where(z <= 0.0, torch.full_like(z, self.epsilon), z)
         log_q = self.encoder.log_density(mu, log_var, z)
         return torch.mean(log_q - self.prior_log_pdf(z), dim=0)
+
+
+class VariationalInferenceReal(VariationalInference):
+    """Real-data objective (model.py:1217-1261): encode the first t0 steps, decode the rest, masked SSE on x[t0:]."""
+
+    def __init__(self, encoder, decoder, elbo=True, prior_log_pdf=None, mc_size=100, t0=24, weight=False):
+        super().__init__(encoder, decoder, elbo, prior_log_pdf, mc_size)
+        self.t0 = t0
+        self.weight = weight
+
+    def loss(self, data):
+        x, a, mask, s = data["measurements"], data["actions"], data["masks"], data["statics"]
+        t0 = self.t0
+        a_in = torch.cat([a, s], dim=-1)
+        mu, log_var = self.encoder(x[:t0], a_in[:t0], mask[:t0])
+        z = self.encoder.reparameterize(mu, log_var) if self.elbo else mu
+        x_hat, h_hat = self.decoder(z, a, s)
+        self.x_hat, self.h_hat, self.z = x_hat, h_hat, z
+        if self.weight:
+            weight = 1 / torch.arange(1, self.decoder.t_max - t0 + 1, device=x.device)[:, None, None]
+        else:
+            weight = 1.0
+        lik = torch.sum((x[t0:] - x_hat) ** 2 * mask[t0:] * weight) / x[t0:].shape[1]
+        if not self.elbo:
+            return lik
+        if self.prior_log_pdf is None:
+            kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+        else:
+            kld = torch.mean(self.mc_kl(mu, log_var, self.mc_size), dim=0)
+        return lik + kld

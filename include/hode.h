@@ -98,7 +98,9 @@ typedef struct hode_solve_desc {
   const float* dosage;     /* ROCHE/NEURAL: [B] (set_action, model.py:498); ROCHE_REAL: [Ta][B] */
   const float* dose_times; /* ROCHE/NEURAL: [B][K] fp32 times (model.py:502-507) */
   const float* theta;      /* ROCHE: [HODE_N_THETA]; ROCHE_REAL: {k_immunity, kel, kel2} */
-  const float* w1;         /* ROCHE: ml_net.0.weight [D-4][D]; NEURAL: [10D][D+1]; REAL: packed (see hode_real.h) */
+  const float* w1;         /* ROCHE: ml_net.0.weight [D-4][D]; NEURAL: [10D][D+1]; REAL: all weights flat in parameter
+                              creation order (model.py:588-607): dx1_net.0.{w[H][3],b[H]}, dx1_net.2.{w[H],b[1]},
+                              dx2_net.0.{w[H][2],b[H]}, dx2_net.2.{w[H],b[1]}, lin_hh, lin_hz, lin_hr [D-4][D-4] */
   const float* b1;         /* ROCHE: ml_net.0.bias [D-4];      NEURAL: [10D] */
   const float* w2;         /* NEURAL: [D][10D] */
   const float* b2;         /* NEURAL: [D] */
@@ -168,6 +170,10 @@ const char* hode_last_error_string(void);
  * u2t[inst][D][B] (inst = (T-1) * stages).  This returns their byte offsets; the caller contracts them:
  * grad_w1 = sum_inst u1t yet^T, grad_b1 = sum u1t, grad_w2 = sum_inst u2t a1t^T, grad_b2 = sum u2t. */
 int hode_neural_tape_offsets(const hode_solve_desc* desc, size_t* out4);
+
+/* HODE_RHS_ROCHE_REAL backward: hode_rk_bwd fills grad_y0 and grad_theta[0..2] (k_immunity, kel, kel2) and tapes the
+ * weight-gradient GEMM operands at the start of the workspace as tape[inst][rows][B], inst = (T-1)*stages,
+ * rows = 5 + 4H + 5(D-4) in the order Y3(3) A11(H) U11(H) U12(1) A21(H) U21(H) U22(1) HH RH UR UZ UH (D-4 each). */
 
 /* bytes of device scratch the given entry point needs for this descriptor (0 if none) */
 size_t hode_workspace_bytes(const hode_solve_desc* desc, int which);
