@@ -1,6 +1,7 @@
 // C-ABI entry points of libhode.so (declared in include/hode.h): argument checks, variant selection, launches.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "hode_host.hpp"
 #include "hode_roche.hpp"
@@ -44,7 +45,24 @@ __global__ __launch_bounds__(64) void fold_partials_kernel(const float* __restri
   }
 }
 
-int n_waves_for(int B, int lpp) { return (int)(((long long)B * lpp + 63) / 64); }
+// patients per wave: as many waves as it takes to put one on (almost) every SIMD, then whole rounds of 1024
+int patients_per_wave(int B, int lpp) {
+  const int cap = 64 / lpp;
+  if (const char* env = getenv("HODE_PPW")) {  // tuning / test override
+    const int v = atoi(env);
+    if (v >= 1 && v <= cap) return v;
+  }
+  const long long simds = 1024;
+  const long long rounds = (B + simds * cap - 1) / (simds * cap);
+  long long ppw = (B + simds * rounds - 1) / (simds * rounds);
+  if (ppw < 1) ppw = 1;
+  if (ppw > cap) ppw = cap;
+  return (int)ppw;
+}
+int n_waves_for(int B, int lpp) {
+  const int ppw = patients_per_wave(B, lpp);
+  return (B + ppw - 1) / ppw;
+}
 
 // LPP = 4 (a patient per DPP quad, 16 patients per wave) fills the chip at the 10k-patient shape; LPP = 1 has
 // the lowest total instruction count and wins once every SIMD has >= 2 waves without splitting patients
@@ -87,10 +105,24 @@ RkArgs make_args(const hode_solve_desc* d) {
   a.w1 = d->w1; a.b1 = d->b1; a.h = d->h; a.grad_h = d->grad_h; a.grad_y0 = d->grad_y0;
   a.partials = (float*)d->workspace; a.status = d->status;
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
+  a.ppw = hode::patients_per_wave(d->batch, choose_lpp(d));
   return a;
 }
 
+// lanes_per_patient == 16 (or HODE_RK_LAYOUT=m) selects the MFMA layout (hode_rk_mf.hip) where it exists for the dimension
+bool use_mf(const hode_solve_desc* d) {
+  if (!hode::mf_supported(d)) return false;
+  if (d->lanes_per_patient == 16) return true;
+  if (d->lanes_per_patient != 0) return false;
+  if (const char* env = getenv("HODE_RK_LAYOUT")) return env[0] == 'm';
+  // measured at 10 000 patients (T=100, D=12, rk4): MFMA layout fwd 118 us / bwd 313 us vs quad layout 104 / 339 -- a
+  // wash (the 3 dependent 16x16x4 MFMAs + hazard nops cost as much latency as the 24 fmas they replace), so the quad
+  // layout stays the default and the MFMA layout is opt-in
+  return false;
+}
+
 int dispatch_dim(const hode_solve_desc* d, bool bwd, hipStream_t s) {
+  if (use_mf(d)) return hode::mf_rk(d, bwd, s);
   RkLaunch L;
   L.method = d->method;
   L.lpp = choose_lpp(d);
@@ -147,7 +179,9 @@ extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
     return hode::real_workspace_bytes(d, which == HODE_WS_RK_BWD);
   switch (which) {
     case HODE_WS_RK_FWD: return 0;
-    case HODE_WS_RK_BWD: return (size_t)n_waves_for(d->batch, choose_lpp(d)) * n_partials(d) * sizeof(float);
+    case HODE_WS_RK_BWD:
+      if (use_mf(d)) return hode::mf_workspace_bytes(d);
+      return (size_t)n_waves_for(d->batch, choose_lpp(d)) * n_partials(d) * sizeof(float);
     case HODE_WS_DOPRI5_FWD:
     case HODE_WS_DOPRI5_BWD: return hode_dopri5_workspace_bytes(d);
     default: return 0;
@@ -174,6 +208,7 @@ extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
     return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   if (int e = dispatch_dim(d, true, s)) return e;
+  if (use_mf(d)) return 0;  // the MFMA-layout path folds its own partials
   const int M = d->latent_dim - 4;
   const int P = n_partials(d);
   const int nw = n_waves_for(d->batch, choose_lpp(d));

@@ -51,6 +51,7 @@ DpArgs dp_args(const hode_solve_desc* d, const DpLayout& L) {
   a.grad_partials = (float*)(ws + L.grad_partials);
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose;
   a.n_waves = hode::n_waves_for(d->batch, hode::choose_lpp(d));
+  a.ppw = hode::patients_per_wave(d->batch, hode::choose_lpp(d));
   a.max_steps = d->max_steps;
   a.rtol = (float)d->rtol; a.atol = (float)d->atol;
   return a;

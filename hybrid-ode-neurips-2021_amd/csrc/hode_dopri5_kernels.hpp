@@ -45,7 +45,7 @@ struct DpArgs {
   const float* __restrict__ grad_h;
   float* __restrict__ grad_y0;
   float* __restrict__ grad_partials;  // [n_waves][P]
-  int B, T, K, n_waves, max_steps, attempt, n_acc;
+  int B, T, K, n_waves, max_steps, attempt, n_acc, ppw;
   float rtol, atol;
 };
 
@@ -119,7 +119,7 @@ HODE_DEV void dp_stages(const RocheTheta& th, const MlSlice<D, LPP>& ml, const D
 template <int D, int LPP, bool ABLATE, bool HILL2, bool K1>
 HODE_DEV void dp_init1_body(const DpArgs& a) {
   using Ml = MlSlice<D, LPP>;
-  const LaneMap<LPP> lm(a.B);
+  const LaneMap<LPP> lm(a.B, a.ppw);
   const RocheTheta th = load_theta(a.theta, ABLATE);
   Ml ml;
   ml.load(a.w1, a.b1, lm.q);
@@ -152,7 +152,7 @@ HODE_DEV void dp_init1_body(const DpArgs& a) {
 template <int D, int LPP, bool ABLATE, bool HILL2, bool K1>
 HODE_DEV void dp_init2_body(const DpArgs& a) {
   using Ml = MlSlice<D, LPP>;
-  const LaneMap<LPP> lm(a.B);
+  const LaneMap<LPP> lm(a.B, a.ppw);
   const RocheTheta th = load_theta(a.theta, ABLATE);
   Ml ml;
   ml.load(a.w1, a.b1, lm.q);
@@ -208,7 +208,7 @@ HODE_DEV void dp_attempt_body(const DpArgs& a) {
   const float* pin = a.partials + (size_t)(par ^ 1) * 2 * a.n_waves;
   float* pout = a.partials + (size_t)par * 2 * a.n_waves;
 
-  const LaneMap<LPP> lm(a.B);
+  const LaneMap<LPP> lm(a.B, a.ppw);
   const size_t row = (size_t)a.B * D;
   const size_t poff = (size_t)lm.p * D;
   const float cnt = (float)a.B * (float)D;
@@ -368,7 +368,7 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
   using Ml = MlSlice<D, LPP>;
   constexpr int MR = Ml::MR;
   constexpr int M = D - 4;
-  const LaneMap<LPP> lm(a.B);
+  const LaneMap<LPP> lm(a.B, a.ppw);
   const RocheTheta th = load_theta(a.theta, ABLATE);
   Ml ml;
   ml.load(a.w1, a.b1, lm.q);

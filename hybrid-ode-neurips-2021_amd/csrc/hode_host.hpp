@@ -23,7 +23,7 @@ struct RkArgs {
   float* __restrict__ grad_y0;
   float* __restrict__ partials;  // [n_waves][P] per-wave parameter-gradient partials (backward)
   int* __restrict__ status;
-  int B, T, K, perturb;
+  int B, T, K, perturb, ppw;
 };
 
 struct RkLaunch {
@@ -55,8 +55,14 @@ int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
 size_t real_workspace_bytes(const hode_solve_desc* d, bool bwd);
 int real_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
 
+// MFMA-layout Roche kernels (hode_rk_mf.hip)
+bool mf_supported(const hode_solve_desc* d);
+size_t mf_workspace_bytes(const hode_solve_desc* d);
+int mf_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
+
 // shared host helpers (hode_api.hip)
 int hip_fail(hipError_t e, const char* what);
+int patients_per_wave(int B, int lpp);
 int n_waves_for(int B, int lpp);
 int choose_lpp(const hode_solve_desc* d);
 int n_partials(const hode_solve_desc* d);

@@ -55,12 +55,18 @@ template <int LPP>
 struct LaneMap {
   int p, q;
   bool live;
-  HODE_DEV LaneMap(int B) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int pp = gid / LPP;
-    q = gid % LPP;
-    live = pp < B;
-    p = live ? pp : B - 1;  // idle lanes shadow the last patient so that cross-lane ops stay well defined
+  // ppw = patients handled by one wave (<= 64 / LPP).  VALU cost is per wave-instruction, not per lane, and extra waves
+  // on one SIMD do not overlap (tools/micro/valu_rate.hip), so at small batches the host lowers ppw until the grid has
+  // about one wave per SIMD (1024): 10 patients per wave at B = 10 000 instead of 16.
+  HODE_DEV LaneMap(int B, int ppw) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int slot = lane / LPP;
+    q = lane % LPP;
+    const int pp = wave * ppw + slot;
+    live = slot < ppw && pp < B;
+    p = live ? pp : min(pp, B - 1);  // idle lanes shadow a valid patient so that cross-lane ops stay well defined
+    if (slot >= ppw) p = min(wave * ppw, B - 1);
   }
 };
 

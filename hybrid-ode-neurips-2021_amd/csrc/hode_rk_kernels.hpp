@@ -60,7 +60,7 @@ template <int D, int LPP, int METHOD, bool ABLATE, bool HILL2, bool K1>
 HODE_DEV void rk_fwd_body(const RkArgs& a) {
   using Ml = MlSlice<D, LPP>;
   constexpr int MR = Ml::MR;
-  const LaneMap<LPP> lm(a.B);
+  const LaneMap<LPP> lm(a.B, a.ppw);
   const RocheTheta th = load_theta(a.theta, ABLATE);
   Ml ml;
   ml.load(a.w1, a.b1, lm.q);
@@ -140,7 +140,7 @@ HODE_DEV void rk_bwd_body(const RkArgs& a) {
   using Ml = MlSlice<D, LPP>;
   constexpr int MR = Ml::MR;
   constexpr int M = D - 4;
-  const LaneMap<LPP> lm(a.B);
+  const LaneMap<LPP> lm(a.B, a.ppw);
   const RocheTheta th = load_theta(a.theta, ABLATE);
   Ml ml;
   ml.load(a.w1, a.b1, lm.q);
@@ -308,7 +308,6 @@ __global__ __launch_bounds__(64) void rk_bwd_kernel(RkArgs a) {
 // ---------------------------------------------------------------------------------------------- launch helpers
 namespace hode {
 
-inline int n_waves_for(int B, int lpp) { return (int)(((long long)B * lpp + 63) / 64); }
 
 template <int D, int LPP, int METHOD, bool ABLATE>
 int launch_fwd(const RkArgs& a, hipStream_t s) {

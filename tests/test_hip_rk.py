@@ -203,3 +203,56 @@ def test_errors_are_loud():
     with pytest.raises(hode.HodeError):  # unsupported latent dim
         roche_solve(torch.zeros(4, 7, device=dev), theta.to(dev), torch.zeros(3, 7, device=dev), torch.zeros(3, device=dev),
                     inp["t"].to(dev), torch.zeros(4, device=dev), torch.zeros(4, 1, device=dev))
+
+
+# ------------------------------------------------------------------------------------------------ MFMA layout (lanes = 16)
+@pytest.mark.parametrize("D", [8, 12])
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_mfma_layout_vs_oracle(D, method):
+    """hode_rk_mf.hip: same contract as the quad layout, matvecs and weight gradients on the matrix pipe."""
+    dev = _dev()
+    N, T = 77, 30
+    inp, f = _case(N, T, D, seed=50 + D)
+    cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(15))
+    _compare(_run_hip(inp, f, method, 16, dev, cot=cot), _run_oracle(inp, f, method, cot=cot))
+
+
+def test_mfma_layout_variants():
+    dev = _dev()
+    cot = torch.randn(25, 40, 12, generator=torch.Generator().manual_seed(16))
+    # perturb, ablate, several doses, general Hill exponents / random theta
+    inp, f = _case(40, 25, 12, seed=61)
+    _compare(_run_hip(inp, f, "rk4", 16, dev, perturb=True, cot=cot), _run_oracle(inp, f, "rk4", perturb=True, cot=cot))
+    inp, f = _case(40, 25, 12, seed=62, ablate=True)
+    _compare(_run_hip(inp, f, "rk4", 16, dev, cot=cot), _run_oracle(inp, f, "rk4", cot=cot))
+    inp, f = _case(40, 25, 12, seed=63, n_dose=3)
+    _compare(_run_hip(inp, f, "rk4", 16, dev, cot=cot), _run_oracle(inp, f, "rk4", cot=cot))
+    theta = (3.0, 1.5, 0.8, 1.3, 0.7, 0.9, 1.1, 0.6, 1.2, 0.5, 1.4, 0.75, 0.65)
+    inp, f = _case(40, 25, 8, seed=64, theta=theta)
+    cot8 = torch.randn(25, 40, 8, generator=torch.Generator().manual_seed(17))
+    _compare(_run_hip(inp, f, "rk4", 16, dev, cot=cot8), _run_oracle(inp, f, "rk4", cot=cot8), g_tol=3e-4)
+    # edge shapes
+    for N, T in ((1, 5), (16, 2), (17, 3), (5, 1)):
+        inp, f = _case(N, T, 12, seed=70 + N)
+        if T < 3:
+            inp["actions"].zero_()
+            if T >= 2:
+                inp["actions"][0, :, 0] = 1.5
+        c = torch.randn(T, N, 12, generator=torch.Generator().manual_seed(18))
+        if float(inp["actions"].abs().sum()) == 0.0:
+            continue
+        _compare(_run_hip(inp, f, "rk4", 16, dev, cot=c), _run_oracle(inp, f, "rk4", cot=c))
+
+
+def test_mfma_layout_agrees_with_quad_layout_at_full_size():
+    dev = _dev()
+    N, T, D = 10000, 100, 12
+    inp, f = _case(N, T, D, seed=666)
+    cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(19))
+    a = _run_hip(inp, f, "rk4", 16, dev, cot=cot)
+    b = _run_hip(inp, f, "rk4", 4, dev, cot=cot)
+    assert (a["h"] - b["h"]).abs().max().item() <= 2e-5 * (1 + b["h"].abs().max().item())
+    for k in ("gy0", "gw", "gb", "gtheta"):
+        assert _rel(a[k], b[k]) <= 1e-4, (k, _rel(a[k], b[k]))
+    a2 = _run_hip(inp, f, "rk4", 16, dev, cot=cot)
+    assert torch.equal(a["gw"], a2["gw"]) and torch.equal(a["gtheta"], a2["gtheta"])  # deterministic fold
