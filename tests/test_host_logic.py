@@ -166,3 +166,58 @@ def test_training_loop_control_flow(tmp_path, capsys):
     assert "Iter 0002 | Total Loss" in out and "Overall best loss" in out
     assert out.count("Iter ") == 3  # improves once (first validation), then two stale validations -> stop
     assert os.path.exists(str(tmp_path) + "/VI_stub.pkl") and best < 1e9
+
+
+def test_neural_and_real_mirrors_surface():
+    """Constructor signatures, model names, state_dict layouts and CPU rhs arithmetic of the NeuralODE / real-data mirrors
+    (reference model.py:969-1026, :570-657, :772-862, :180-242) against golden G2 / G3 / G4."""
+    torch.manual_seed(0)
+    dec = model.RocheExpertDecoder(40, 8, 1, 1.0, 0.125, roche=False, method="rk4", device=CPU)
+    assert dec.model_name == "NeuralODEDecoder"
+    assert list(dec.state_dict()) == ["output_function.0.weight", "output_function.0.bias", "ode.kel", "ode.ml_net.0.weight",
+                                      "ode.ml_net.0.bias", "ode.ml_net.2.weight", "ode.ml_net.2.bias"]
+    assert dec.ode.ml_net[0].weight.shape == (80, 9) and dec.ode.ml_net[2].weight.shape == (8, 80)
+    dr = model.DecoderReal(24, 20, 1, 11, 43, 40, 1, method="midpoint", ode_step_size=1.0, ode_type="hybrid", t0=24, device=CPU)
+    assert dr.model_name == "DecoderReal_hybrid" and dr.t.tolist() == [float(v) for v in range(23, 40)]
+    keys = list(dr.state_dict())
+    assert keys[:4] == ["output_function.0.weight", "output_function.0.bias", "output_function.2.weight", "output_function.2.bias"]
+    assert keys[4:] == ["ode.k_immunity", "ode.kel", "ode.kel2", "ode.dx1_net.0.weight", "ode.dx1_net.0.bias", "ode.dx1_net.2.weight",
+                        "ode.dx1_net.2.bias", "ode.dx2_net.0.weight", "ode.dx2_net.0.bias", "ode.dx2_net.2.weight", "ode.dx2_net.2.bias",
+                        "ode.lin_hh.weight", "ode.lin_hz.weight", "ode.lin_hr.weight"]
+    assert dr.ode.flat_weights().numel() == 9 * 43 + 2 + 3 * 16 * 16
+    enc = model.EncoderLSTMReal(37, 44, 20, output_all=False, reverse=False, device=CPU)
+    assert enc.model_name == "LSTMReal" and list(enc.state_dict())[:4] == ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0"]
+    with pytest.raises(RuntimeError):
+        model.DecoderReal(24, 20, 1, 11, 43, 40, 1, ode_type="neural", device=CPU)
+
+
+def test_real_mirror_cpu_arithmetic_matches_golden(golden_dir):
+    g = _load(golden_dir, "g3_roche_real_rhs.npz")
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d_" % ci
+        D, H, T, B = [int(v) for v in g[pre + "meta"]]
+        ode = model.RocheODEReal(D, 1, 11, H, T, 1, device=CPU)
+        ode.load_state_dict({k[len(pre + "sd_"):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pre + "sd_")})
+        ode.set_action_static(torch.from_numpy(g[pre + "action"]), None)
+        y = torch.from_numpy(g[pre + "y"])
+        for ti, t in enumerate(g[pre + "t"]):
+            tt = torch.tensor(float(t))
+            np.testing.assert_allclose(ode(tt, y).detach().numpy(), g[pre + "f"][ti], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(ode.dose_at_time(tt).detach().numpy(), g[pre + "dose"][ti], rtol=1e-6, atol=1e-7)
+    g4 = _load(golden_dir, "g4_encoder.npz")
+    obs, aw, H, Dz, T, B = [int(v) for v in g4["real_meta"]]
+    enc = model.EncoderLSTMReal(obs + aw + 1, H, Dz, output_all=False, reverse=False, device=CPU)
+    enc.load_state_dict({k[len("real_sd_"):].replace("__", "."): torch.from_numpy(g4[k]) for k in g4.files if k.startswith("real_sd_")})
+    mu, lv = enc(torch.from_numpy(g4["real_x"]), torch.from_numpy(g4["real_a"]), torch.from_numpy(g4["real_mask"]))
+    np.testing.assert_allclose(mu.detach().numpy(), g4["real_mu"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(lv.detach().numpy(), g4["real_log_var"], rtol=2e-5, atol=2e-6)
+    gn = _load(golden_dir, "g2_neural_rhs.npz")
+    for ci in range(int(gn["n_cases"])):
+        pre = "c%d_" % ci
+        D, T, B = [int(v) for v in gn[pre + "meta"]]
+        ode = model.NeuralODE(D, 1, (T - 1) * 0.125, float(gn[pre + "step"]), device=CPU)
+        ode.load_state_dict({k[len(pre + "sd_"):].replace("__", "."): torch.from_numpy(gn[k]) for k in gn.files if k.startswith(pre + "sd_")})
+        ode.set_action(torch.from_numpy(gn[pre + "action"]))
+        y = torch.from_numpy(gn[pre + "y"])
+        for ti, t in enumerate(gn[pre + "t"]):
+            np.testing.assert_allclose(ode(torch.tensor(float(t)), y).detach().numpy(), gn[pre + "f"][ti], rtol=1e-6, atol=1e-7)
