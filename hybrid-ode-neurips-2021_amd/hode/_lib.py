@@ -62,6 +62,16 @@ class LstmDesc(C.Structure):
     ]
 
 
+class ReadoutDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("latent_dim", C.c_int32), ("obs_dim", C.c_int32), ("scale", C.c_float),
+        ("rows", C.c_int64),
+        ("h", _fp), ("x", _fp), ("mask", _fp), ("w", _fp), ("b", _fp), ("lik", _fp),
+        ("grad_h", _fp), ("grad_w", _fp), ("grad_b", _fp),
+        ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 #: every symbol include/hode.h declares: (name, restype, argtypes)
 EXPORTS = (
     ("hode_version", C.c_int, ()),
@@ -73,6 +83,8 @@ EXPORTS = (
     ("hode_rk_bwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
     ("hode_dopri5_fwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
     ("hode_dopri5_bwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
+    ("hode_readout_workspace_bytes", C.c_size_t, (C.POINTER(ReadoutDesc),)),
+    ("hode_readout_sse", C.c_int, (C.POINTER(ReadoutDesc), C.c_void_p)),
     ("hode_lstm_fwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
     ("hode_lstm_bwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
 )

@@ -253,11 +253,25 @@ class RocheExpertDecoder(nn.Module):
             self.ode = NeuralODE(latent_dim, action_dim, t_max, step_size, self.device)
         self._odeint = hode.odeint  # tests swap in the CPU oracle here; the product path never does
 
-    def forward(self, init, a):
+    def latent(self, init, a):
+        """Latent trajectory h (T, B, D) only."""
         self.ode.set_action(a)
-        h = self._odeint(self.ode, init, self.t, rtol=self.options["rtol"], atol=self.options["atol"],
-                         method=self.options["method"])
+        return self._odeint(self.ode, init, self.t, rtol=self.options["rtol"], atol=self.options["atol"],
+                            method=self.options["method"])
+
+    def forward(self, init, a):
+        h = self.latent(init, a)
         return self.output_function(h), h
+
+    def fused_likelihood_ok(self, x):
+        from hode import readout
+        return x.is_cuda and self._odeint is hode.odeint and readout.supported(self.latent_dim, self.obs_dim)
+
+    def masked_sse(self, h, x, mask):
+        """sum((x - output_function(h))^2 * mask) / B in one fused pass (x_hat never hits HBM)."""
+        from hode import readout
+        lin = self.output_function[0]
+        return readout.masked_sse_readout(h, x, mask, lin.weight, lin.bias)
 
 
 class EncoderLSTMReal(nn.Module, GaussianReparam):
@@ -403,6 +417,7 @@ class VariationalInference:
         self.prior_log_pdf = prior_log_pdf
         self.mc_size = mc_size
         self.elbo = elbo
+        self.fuse_likelihood = True  # fused readout + masked-SSE kernel when the decoder supports the shape
         self.model_name = "VI_{}_{}.pkl".format(encoder.model_name, decoder.model_name)
 
     def save(self, path, itr, best_loss):
@@ -421,9 +436,16 @@ class VariationalInference:
         self.mu, self.log_var = mu, log_var
         z = self.encoder.reparameterize(mu, log_var) if self.elbo else mu
         self.z = z
-        x_hat, h_hat = self.decoder(z, a)
-        self.x_hat, self.h_hat = x_hat, h_hat
-        lik = torch.sum((x - x_hat) ** 2 * mask) / x.shape[1]
+        fused = getattr(self.decoder, "fused_likelihood_ok", None)
+        if self.fuse_likelihood and fused is not None and fused(x):
+            # readout + masked SSE (+ gradients) in one HBM pass; x_hat is produced only if somebody reads vi.x_hat
+            h_hat = self.decoder.latent(z, a)
+            self.h_hat, self._x_hat = h_hat, None
+            lik = self.decoder.masked_sse(h_hat, x, mask)
+        else:
+            x_hat, h_hat = self.decoder(z, a)
+            self._x_hat, self.h_hat = x_hat, h_hat
+            lik = torch.sum((x - x_hat) ** 2 * mask) / x.shape[1]
         if not self.elbo:
             return lik
         if self.prior_log_pdf is None:
@@ -431,6 +453,17 @@ class VariationalInference:
         else:
             kld = torch.mean(self.mc_kl(mu, log_var, self.mc_size), dim=0)
         return lik + kld
+
+    @property
+    def x_hat(self):
+        if getattr(self, "_x_hat", None) is None and getattr(self, "h_hat", None) is not None:
+            with torch.no_grad():
+                self._x_hat = self.decoder.output_function(self.h_hat)
+        return self._x_hat
+
+    @x_hat.setter
+    def x_hat(self, value):
+        self._x_hat = value
 
     def mc_kl(self, mu, log_var, sample_size):
         """E_q[log q - log p] from `sample_size` draws, non-positive draws clamped to eps.  All draws in one batched

@@ -158,6 +158,27 @@ typedef struct hode_lstm_desc {
   size_t workspace_bytes;
 } hode_lstm_desc;
 
+/* Fused readout + masked SSE (reference model.py:1120 x_hat = Linear(D -> obs)(h) and model.py:1179
+ * lik = sum((x - x_hat)^2 * mask) / B, plus their autograd backward) without materialising x_hat. */
+typedef struct hode_readout_desc {
+  uint32_t struct_size;
+  int32_t latent_dim;   /* D */
+  int32_t obs_dim;      /* obs (multiple of 4, <= 128) */
+  float scale;          /* 1 / B: folded into the gradients (lik itself is returned as the plain sum) */
+  int64_t rows;         /* T * B rows of h / x / mask */
+  const float* h;       /* [rows][D] */
+  const float* x;       /* [rows][obs] */
+  const float* mask;    /* [rows][obs] */
+  const float* w;       /* output_function.0.weight [obs][D] */
+  const float* b;       /* output_function.0.bias [obs] */
+  float* lik;           /* out [1]: sum((x - x_hat)^2 * mask) */
+  float* grad_h;        /* out [rows][D] or NULL for the loss only: d(scale * lik)/dh */
+  float* grad_w;        /* acc [obs][D]: d(scale * lik)/dW */
+  float* grad_b;        /* acc [obs] */
+  void* workspace;      /* >= hode_readout_workspace_bytes */
+  size_t workspace_bytes;
+} hode_readout_desc;
+
 #define HODE_WS_RK_FWD 0
 #define HODE_WS_RK_BWD 1
 #define HODE_WS_DOPRI5_FWD 2
@@ -189,6 +210,9 @@ int hode_rk_bwd(const hode_solve_desc* desc, void* hip_stream);
  * Synchronises the stream once per chunk of attempts to read the controller record. */
 int hode_dopri5_fwd(const hode_solve_desc* desc, void* hip_stream);
 int hode_dopri5_bwd(const hode_solve_desc* desc, void* hip_stream);
+
+size_t hode_readout_workspace_bytes(const hode_readout_desc* desc);
+int hode_readout_sse(const hode_readout_desc* desc, void* hip_stream);
 
 int hode_lstm_fwd(const hode_lstm_desc* desc, void* hip_stream);
 int hode_lstm_bwd(const hode_lstm_desc* desc, void* hip_stream);
