@@ -116,8 +116,10 @@ def pmc_traffic():
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if "rk_bwd_kernel<12" in k and "hbm_bytes_per_launch" in v:
-                best = {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
+            if ("split_bwd_kernel<12" in k or "rk_bwd_kernel<12" in k) and "hbm_bytes_per_launch" in v:
+                if best is not None and "split" in best.get("kernel", "") and "split" not in k:
+                    continue
+                best = {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "kernel": k}
     return best
 
 
@@ -246,11 +248,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "dim12 synthetic, %d patients/GPU, T=%d, dt=0.125, rk4(3/8), fused rhs+step kernel "
-                                   "+ discrete-adjoint kernel" % (N_PER_GPU, T),
+                                   "+ discrete-adjoint kernel (split expert/learned wave pipelines)" % (N_PER_GPU, T),
                        "patients_total": total, "launch": "hipGraph" if use_graph else "eager",
                        "lanes_per_patient": args.lanes or "auto", "theta_grad": not args.no_theta_grad,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "rk_bwd_kernel<12,...> (+fold_partials)", "achieved": ach,
+            "roofline": {"bound": "hbm", "kernel": "split_bwd_kernel<12,rk4> (+fold_partials)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": plan.bwd_bytes, "avg_launch_us": bwd_s * 1e6,
                          "fwd": {"bytes_per_launch": plan.fwd_bytes, "avg_launch_us": fwd_s * 1e6,

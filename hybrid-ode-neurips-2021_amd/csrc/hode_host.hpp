@@ -60,6 +60,12 @@ bool mf_supported(const hode_solve_desc* d);
 size_t mf_workspace_bytes(const hode_solve_desc* d);
 int mf_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
 
+// wave-specialised split layout (hode_rk_split.hip)
+bool split_supported(const hode_solve_desc* d);
+int split_rk_fwd(const hode_solve_desc* d, hipStream_t s);
+size_t split_workspace_bytes(const hode_solve_desc* d);
+int split_rk_bwd(const hode_solve_desc* d, hipStream_t s);
+
 // shared host helpers (hode_api.hip)
 int hip_fail(hipError_t e, const char* what);
 int patients_per_wave(int B, int lpp);

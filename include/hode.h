@@ -91,7 +91,8 @@ typedef struct hode_solve_desc {
   int32_t hidden_dim;     /* NEURAL: 10*D; ROCHE_REAL: MLP hidden width */
   int32_t n_action_times; /* ROCHE_REAL: length of the dose table along time */
   int32_t lanes_per_patient; /* 0 = library chooses; forces a variant (tuning / tests): 1 = lane per patient,
-                                4 = patient per DPP quad, 16 = MFMA layout (4 lanes strided by 16, D in {8,12,16}) */
+                                4 = patient per DPP quad, 16 = MFMA layout (4 lanes strided by 16, D in {8,12,16}),
+                                48 = split layout (expert wave + learned waves per 48 patients, D in {8,12}; default there) */
   int32_t need_theta_grad;   /* backward: also accumulate grad_theta */
 
   const float* t;          /* [T] output grid == step grid (model.py:1072); strictly increasing */

@@ -256,3 +256,23 @@ def test_mfma_layout_agrees_with_quad_layout_at_full_size():
         assert _rel(a[k], b[k]) <= 1e-4, (k, _rel(a[k], b[k]))
     a2 = _run_hip(inp, f, "rk4", 16, dev, cot=cot)
     assert torch.equal(a["gw"], a2["gw"]) and torch.equal(a["gtheta"], a2["gtheta"])  # deterministic fold
+
+
+# ------------------------------------------------------------------------------------------------ split layout (lanes = 48)
+@pytest.mark.parametrize("D", [8, 12])
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_split_layout_forward_vs_oracle(D, method):
+    """hode_rk_split.hip: expert wave + learned waves through an LDS ring; forward kernel (backward = quad layout)."""
+    dev = _dev()
+    for N, T, perturb in ((77, 30, False), (48, 3, True), (1, 9, False), (150, 2, False)):
+        inp, f = _case(N, T, D, seed=80 + D + N)
+        if T < 3:
+            inp["actions"].zero_()
+            inp["actions"][0, :, 0] = 1.5
+        cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(21))
+        _compare(_run_hip(inp, f, method, 48, dev, perturb=perturb, cot=cot), _run_oracle(inp, f, method, perturb=perturb, cot=cot))
+    inp, f = _case(40, 20, D, seed=90, ablate=True)
+    cot = torch.randn(20, 40, D, generator=torch.Generator().manual_seed(22))
+    _compare(_run_hip(inp, f, method, 48, dev, cot=cot), _run_oracle(inp, f, method, cot=cot))
+    inp, f = _case(40, 20, D, seed=91, n_dose=2)
+    _compare(_run_hip(inp, f, method, 48, dev, cot=cot), _run_oracle(inp, f, method, cot=cot))
