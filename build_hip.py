@@ -16,6 +16,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-Wno-unused-but-set-variable"]
 RK_DIMS = (4, 6, 8, 12, 20)
 DP_DIMS = (4, 6, 8, 12)
+# per-unit flags (measured on MI355X)
+# -fno-slp-vectorize on the split kernels: packed-fp32 pairing costs more v_mov than it saves (step 0.228 -> 0.207 ms)
+EXTRA_FLAGS = {"hode_rk_split": os.environ.get("HODE_SPLIT_FLAGS", "-fno-slp-vectorize").split()}
 
 
 def units():
@@ -27,7 +30,7 @@ def units():
     for name in ("hode_dopri5", "hode_lstm", "hode_neural", "hode_real", "hode_rk_mf", "hode_readout", "hode_rk_split"):
         src = os.path.join(CSRC, name + ".hip")
         if os.path.exists(src):
-            u.append((name, src, []))
+            u.append((name, src, EXTRA_FLAGS.get(name, [])))
     return u
 
 
