@@ -79,11 +79,22 @@ HODE_DEV DoseSched<K1> dp_load_dose(const DpArgs& a, int p) {
   return ds;
 }
 
-// fold this launch's view of a per-wave partial array (fixed order => identical result in every lane of every wave)
+// fold this launch's view of a per-wave partial array (fixed order => identical result in every lane of every wave).
+// The loads of a lane are issued together (16 in flight) before they are summed: a dependent load-add chain here costs
+// one L2 round trip per 64 partials on EVERY attempt.
 HODE_DEV float fold_waves(const float* __restrict__ part, int n_waves, int stride, int off) {
   const int lane = threadIdx.x & 63;
   float s = 0.f;
-  for (int w = lane; w < n_waves; w += 64) s += part[(size_t)w * stride + off];
+  for (int base = 0; base < n_waves; base += 64 * 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int w = base + lane + 64 * j;
+      v[j] = w < n_waves ? part[(size_t)w * stride + off] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += v[j];
+  }
   return wave_sum(s);
 }
 
