@@ -404,6 +404,14 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     load_own(a.grad_h + (size_t)(T - 1) * row + (size_t)p * D, lam);
 #pragma unroll
     for (int r = 0; r < MR; ++r) lam[r] *= lv;
+    // the operands of iteration k+1 are fetched during iteration k (the state is needed by the very first instruction of
+    // an iteration: an un-hidden HBM round trip would cost a quarter of it)
+    float yo_nx[MR] = {}, gh_nx[MR] = {};
+    {
+      const int m0 = T >= 2 ? T - 2 : 0;
+      load_own(a.h + (size_t)m0 * row + (size_t)p * D, yo_nx);
+      load_own(a.grad_h + (size_t)m0 * row + (size_t)p * D, gh_nx);
+    }
     __syncthreads();  // the expert wave's prologue fills ring 0
     for (int k = 0; k < T; ++k) {
       if (k <= T - 2) {
@@ -411,8 +419,16 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         const int par = k & 1;
         const float dt = a.t[m + 1] - a.t[m];
         float yo[MR], gh[MR];
-        load_own(a.h + (size_t)m * row + (size_t)p * D, yo);
-        load_own(a.grad_h + (size_t)m * row + (size_t)p * D, gh);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+          yo[r] = yo_nx[r];
+          gh[r] = gh_nx[r];
+        }
+        {
+          const int mn = m >= 1 ? m - 1 : 0;  // clamped: the last prefetch is simply unused
+          load_own(a.h + (size_t)mn * row + (size_t)p * D, yo_nx);
+          load_own(a.grad_h + (size_t)mn * row + (size_t)p * D, gh_nx);
+        }
         // ---- recompute the learned stage derivatives
         float Y[4][D], so[4][MR] = {};
 #pragma unroll
