@@ -152,18 +152,22 @@ def full_step_ms(dev, iters=5):
 
 
 def kernel_times(plan, iters=20):
-    """Average duration of the forward and backward launches, HIP events on the launch stream (torch's current)."""
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
+    """Average duration of the forward kernel and of the adjoint kernel ALONE (no memset, no partial fold -- the quantity
+    rocprofv3's kernel stats report), plus the whole backward call, from HIP events on the launch stream."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
     for i in range(iters):
         ev[i][0].record()
         plan.forward()
         ev[i][1].record()
-        plan.backward()
+        plan.backward_kernel_only()
         ev[i][2].record()
+        plan.backward()
+        ev[i][3].record()
     torch.cuda.synchronize()
     fwd = statistics.mean(e[0].elapsed_time(e[1]) for e in ev) * 1e-3
-    bwd = statistics.mean(e[1].elapsed_time(e[2]) for e in ev) * 1e-3
-    return fwd, bwd
+    bwd_kernel = statistics.mean(e[1].elapsed_time(e[2]) for e in ev) * 1e-3
+    bwd_call = statistics.mean(e[2].elapsed_time(e[3]) for e in ev) * 1e-3
+    return fwd, bwd_kernel, bwd_call
 
 
 def main():
@@ -230,7 +234,7 @@ def main():
 
     out = None
     if rank == 0:
-        fwd_s, bwd_s = kernel_times(plan)
+        fwd_s, bwd_s, bwd_call_s = kernel_times(plan)
         ms = elapsed / args.steps * 1e3
         total = N_PER_GPU * world
         ach = plan.bwd_bytes / bwd_s / 1e9
@@ -252,9 +256,10 @@ def main():
                        "patients_total": total, "launch": "hipGraph" if use_graph else "eager",
                        "lanes_per_patient": args.lanes or "auto", "theta_grad": not args.no_theta_grad,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "split_bwd_kernel<12,rk4> (+fold_partials)", "achieved": ach,
+            "roofline": {"bound": "hbm", "kernel": "split_bwd_kernel<12, rk4> (adjoint kernel alone; the whole backward call incl. "
+                                                      "accumulator memset and partial folds is bwd_call_us)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_launch": plan.bwd_bytes, "avg_launch_us": bwd_s * 1e6,
+                         "bytes_per_launch": plan.bwd_bytes, "avg_launch_us": bwd_s * 1e6, "bwd_call_us": bwd_call_s * 1e6,
                          "fwd": {"bytes_per_launch": plan.fwd_bytes, "avg_launch_us": fwd_s * 1e6,
                                  "achieved": plan.fwd_bytes / fwd_s / 1e9},
                          "step_frac": (plan.fwd_bytes + plan.bwd_bytes) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},

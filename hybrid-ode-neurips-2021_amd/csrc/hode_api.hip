@@ -225,6 +225,7 @@ extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int e = dispatch_dim(d, true, s)) return e;
   if (use_split(d, true) || use_mf(d)) return 0;  // these layouts fold their own partials
+  if (d->flags & HODE_FLAG_SKIP_FOLD) return 0;
   const int M = d->latent_dim - 4;
   const int P = n_partials(d);
   const int nw = n_waves_for(d->batch, choose_lpp(d));

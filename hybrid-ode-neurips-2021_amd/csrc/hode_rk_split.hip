@@ -635,7 +635,7 @@ int split_rk_bwd(const hode_solve_desc* d, hipStream_t s) {
   int e;
   if (d->latent_dim == 8) e = abl ? split_bwd_method<8, true>(d, a, s) : split_bwd_method<8, false>(d, a, s);
   else e = abl ? split_bwd_method<12, true>(d, a, s) : split_bwd_method<12, false>(d, a, s);
-  if (e) return e;
+  if (e || (d->flags & HODE_FLAG_SKIP_FOLD)) return e;
   if (int e2 = launch_fold_partials(a.part_ml, 3 * nblk, Pml, M * d->latent_dim, M, d->grad_w1, d->grad_b1, nullptr, 0, s)) return e2;
   return launch_fold_partials(a.part_th, nblk, kNTheta, 0, 0, nullptr, nullptr, d->grad_theta, d->need_theta_grad, s);
 }

@@ -16,6 +16,7 @@ METHODS = {"euler": METHOD_EULER, "midpoint": METHOD_MIDPOINT, "rk4": METHOD_RK4
 N_THETA = 16
 STATUS_NONFINITE, STATUS_DT_UNDERFLOW, STATUS_MAX_STEPS = 1, 2, 4
 WS_RK_FWD, WS_RK_BWD, WS_DOPRI5_FWD, WS_DOPRI5_BWD = 0, 1, 2, 3
+FLAG_SKIP_FOLD = 1
 
 
 class HodeError(RuntimeError):
@@ -45,7 +46,7 @@ class SolveDesc(C.Structure):
         ("grad_h", _fp), ("grad_y0", _fp), ("grad_w1", _fp), ("grad_b1", _fp), ("grad_w2", _fp),
         ("grad_b2", _fp), ("grad_theta", _fp),
         ("rtol", C.c_double), ("atol", C.c_double),
-        ("max_steps", C.c_int32), ("reserved0", C.c_int32),
+        ("max_steps", C.c_int32), ("flags", C.c_int32),
         ("host_n_accepted", C.POINTER(C.c_int32)), ("host_n_rejected", C.POINTER(C.c_int32)),
         ("workspace", _fp), ("workspace_bytes", C.c_size_t),
     ]

@@ -81,6 +81,14 @@ class RocheRKPlan:
         L.check(self.lib.hode_rk_bwd(self.desc, torch.cuda.current_stream().cuda_stream), "hode_rk_bwd")
         return self.grad_y0, self.grad_flat
 
+    def backward_kernel_only(self):
+        """The adjoint kernel alone (HODE_FLAG_SKIP_FOLD, no accumulator memset): what a profiler reports as one kernel."""
+        self.desc.flags = L.FLAG_SKIP_FOLD
+        try:
+            L.check(self.lib.hode_rk_bwd(self.desc, torch.cuda.current_stream().cuda_stream), "hode_rk_bwd")
+        finally:
+            self.desc.flags = 0
+
     def step(self):
         self.forward()
         return self.backward()

@@ -54,6 +54,10 @@ extern "C" {
 #define HODE_METHOD_MIDPOINT 1
 #define HODE_METHOD_RK4_38 2
 
+/* descriptor flags */
+#define HODE_FLAG_SKIP_FOLD 1 /* backward: leave the per-wave gradient partials unfolded (diagnostics: lets a caller time
+                                the adjoint kernel alone; grad_w1 / grad_b1 / grad_theta are then NOT updated) */
+
 /* argument errors */
 #define HODE_E_NULL -1      /* a required pointer is NULL */
 #define HODE_E_SIZE -2      /* struct_size mismatch / non-positive dimension */
@@ -121,7 +125,7 @@ typedef struct hode_solve_desc {
   /* adaptive (dopri5) */
   double rtol, atol;       /* reference passes 1e-7 / 1e-8 (model.py:1079-1080) */
   int32_t max_steps;       /* tape capacity in accepted steps */
-  int32_t reserved0;
+  int32_t flags;           /* HODE_FLAG_* (0 in normal use) */
   int32_t* host_n_accepted; /* HOST out (dopri5_fwd): accepted steps written to the tape */
   int32_t* host_n_rejected; /* HOST out (dopri5_fwd) */
 

@@ -72,8 +72,16 @@ def test_workspace_query(lib):
     d.batch, d.latent_dim, d.n_times = 10000, 12, 100
     P = 8 * 12 + 8 + 15
     assert lib.hode_workspace_bytes(d, L.WS_RK_FWD) == 0
+    d.lanes_per_patient = 4  # quad layout: one partial row [w | b | theta] per wave
     n = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
-    assert n % (P * 4) == 0 and n // (P * 4) >= (10000 + 63) // 64  # one partial row per wave
+    assert n % (P * 4) == 0 and n // (P * 4) >= (10000 + 15) // 16
+    d.lanes_per_patient = 0  # default at D = 12: split layout, 3 learned-wave rows + one theta row per 48 patients
+    nblk = (10000 + 47) // 48
+    n = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
+    assert n % 256 == 0 and n >= nblk * (3 * (8 * 12 + 8) + 15) * 4
+    d.latent_dim = 20  # no split layout for D = 20: quad
+    n20 = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
+    assert n20 % ((16 * 20 + 16 + 15) * 4) == 0
 
 
 def test_missing_library_fails_loudly(tmp_path):
