@@ -68,7 +68,7 @@ def build(jobs=7, force=False, verbose=True):
                 print(err[-2000:], file=sys.stderr)
     objs = [os.path.join(OBJ, n + ".o") for n, _, _ in us]
     if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(o) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])

@@ -214,15 +214,25 @@ extern "C" int hode_rk_fwd(const hode_solve_desc* d, void* stream) {
 }
 
 extern "C" int hode_rk_bwd(const hode_solve_desc* d, void* stream) {
-  if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_NEURAL)
-    return hode::neural_rk(d, true, (hipStream_t)stream);
-  if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_ROCHE_REAL)
-    return hode::real_rk(d, true, (hipStream_t)stream);
+  if (d && d->struct_size == sizeof(hode_solve_desc) &&
+      (d->rhs_kind == HODE_RHS_NEURAL || d->rhs_kind == HODE_RHS_ROCHE_REAL)) {
+    if (d->flags & HODE_FLAG_OVERWRITE_GRADS)
+      return hode::fail(HODE_E_UNSUPPORTED, "HODE_FLAG_OVERWRITE_GRADS is only implemented for the ROCHE rhs kinds");
+    return d->rhs_kind == HODE_RHS_NEURAL ? hode::neural_rk(d, true, (hipStream_t)stream)
+                                          : hode::real_rk(d, true, (hipStream_t)stream);
+  }
   if (int e = check_rk(d, true)) return e;
   const size_t need = hode_workspace_bytes(d, HODE_WS_RK_BWD);
   if (!d->workspace || d->workspace_bytes < need)
     return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
+  if ((d->flags & HODE_FLAG_OVERWRITE_GRADS) && !use_split(d, true)) {
+    // the split layout's fold stores directly; the other layouts accumulate, so clear the outputs first
+    const size_t M = d->latent_dim - 4;
+    if (d->grad_w1) if (int e = hode::hip_fail(hipMemsetAsync(d->grad_w1, 0, M * d->latent_dim * sizeof(float), s), "grad_w1 clear")) return e;
+    if (d->grad_b1) if (int e = hode::hip_fail(hipMemsetAsync(d->grad_b1, 0, M * sizeof(float), s), "grad_b1 clear")) return e;
+    if (d->grad_theta) if (int e = hode::hip_fail(hipMemsetAsync(d->grad_theta, 0, hode::kNTheta * sizeof(float), s), "grad_theta clear")) return e;
+  }
   if (int e = dispatch_dim(d, true, s)) return e;
   if (use_split(d, true) || use_mf(d)) return 0;  // these layouts fold their own partials
   if (d->flags & HODE_FLAG_SKIP_FOLD) return 0;

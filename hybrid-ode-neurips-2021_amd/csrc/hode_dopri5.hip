@@ -141,6 +141,8 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
 
 extern "C" int hode_dopri5_bwd(const hode_solve_desc* d, void* stream) {
   if (int e = check_dp(d, true)) return e;
+  if (d->flags & HODE_FLAG_OVERWRITE_GRADS)
+    return hode::fail(HODE_E_UNSUPPORTED, "HODE_FLAG_OVERWRITE_GRADS is only implemented by hode_rk_bwd");
   hipStream_t s = (hipStream_t)stream;
   const DpLayout lay = dp_layout(d);
   DpArgs a = dp_args(d, lay);

@@ -557,6 +557,40 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   }
 }
 
+// One launch folds both partial arrays of the split backward in a fixed order (deterministic): block j < P_ml sums column j
+// of part_ml over its 3*nblk rows into grad_w1 / grad_b1, the remaining kNTheta blocks sum part_th into grad_theta.
+// overwrite != 0 stores instead of accumulating (saves the caller's memset of the accumulators).
+__global__ __launch_bounds__(64) void split_fold_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_th,
+                                                        int nblk, int P_ml, int n_w, float* __restrict__ gw,
+                                                        float* __restrict__ gb, float* __restrict__ gth, int need_th,
+                                                        int overwrite) {
+  const int j = blockIdx.x;
+  const int lane = threadIdx.x;
+  const bool ml = j < P_ml;
+  const float* src = ml ? part_ml + j : part_th + (j - P_ml);
+  const int rows = ml ? 3 * nblk : nblk;
+  const int stride = ml ? P_ml : kNTheta;
+  float s = 0.f;
+  for (int base = 0; base < rows; base += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int w = base + lane + 64 * q;
+      v[q] = w < rows ? src[(size_t)w * stride] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  s = wave_sum(s);
+  if (lane != 0) return;
+  float* dst = nullptr;
+  if (ml) dst = j < n_w ? (gw ? gw + j : nullptr) : (gb ? gb + (j - n_w) : nullptr);
+  else if (gth) dst = gth + (j - P_ml);
+  if (!dst) return;
+  if (!ml && !need_th) s = 0.f;
+  *dst = overwrite ? s : *dst + s;
+}
+
 template <int D, int METHOD, bool ABLATE, bool NEED_TH>
 __global__ __launch_bounds__(256) void split_bwd_kernel(SplitBwdArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
@@ -636,8 +670,11 @@ int split_rk_bwd(const hode_solve_desc* d, hipStream_t s) {
   if (d->latent_dim == 8) e = abl ? split_bwd_method<8, true>(d, a, s) : split_bwd_method<8, false>(d, a, s);
   else e = abl ? split_bwd_method<12, true>(d, a, s) : split_bwd_method<12, false>(d, a, s);
   if (e || (d->flags & HODE_FLAG_SKIP_FOLD)) return e;
-  if (int e2 = launch_fold_partials(a.part_ml, 3 * nblk, Pml, M * d->latent_dim, M, d->grad_w1, d->grad_b1, nullptr, 0, s)) return e2;
-  return launch_fold_partials(a.part_th, nblk, kNTheta, 0, 0, nullptr, nullptr, d->grad_theta, d->need_theta_grad, s);
+  const bool th_out = d->grad_theta != nullptr && (d->need_theta_grad || (d->flags & HODE_FLAG_OVERWRITE_GRADS));
+  hipLaunchKernelGGL(split_fold_kernel, dim3(Pml + (th_out ? kNTheta : 0)), dim3(64), 0, s, a.part_ml, a.part_th, nblk, Pml,
+                     M * d->latent_dim, d->grad_w1, d->grad_b1, d->grad_theta, d->need_theta_grad,
+                     (d->flags & HODE_FLAG_OVERWRITE_GRADS) ? 1 : 0);
+  return hip_fail(hipGetLastError(), "split_fold launch");
 }
 
 int split_rk_fwd(const hode_solve_desc* d, hipStream_t s) {

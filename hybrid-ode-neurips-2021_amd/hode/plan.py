@@ -59,6 +59,7 @@ class RocheRKPlan:
         nbytes = self.lib.hode_workspace_bytes(d, L.WS_RK_BWD)
         self.ws = torch.empty(max(nbytes, 4), device=self.dev, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
+        d.flags = L.FLAG_OVERWRITE_GRADS
         self.desc = d
         self._graph = None
 
@@ -76,8 +77,8 @@ class RocheRKPlan:
         return self.h
 
     def backward(self):
-        """Discrete adjoint for the cotangent currently in ``self.grad_h``; accumulates into ``grad_flat``."""
-        self.grad_flat.zero_()
+        """Discrete adjoint for the cotangent currently in ``self.grad_h``; overwrites ``grad_flat``
+        (HODE_FLAG_OVERWRITE_GRADS: the fold stores, so no memset of the bucket is needed)."""
         L.check(self.lib.hode_rk_bwd(self.desc, torch.cuda.current_stream().cuda_stream), "hode_rk_bwd")
         return self.grad_y0, self.grad_flat
 
@@ -87,7 +88,7 @@ class RocheRKPlan:
         try:
             L.check(self.lib.hode_rk_bwd(self.desc, torch.cuda.current_stream().cuda_stream), "hode_rk_bwd")
         finally:
-            self.desc.flags = 0
+            self.desc.flags = L.FLAG_OVERWRITE_GRADS
 
     def step(self):
         self.forward()

@@ -58,6 +58,9 @@ extern "C" {
 #define HODE_FLAG_SKIP_FOLD 1 /* backward: leave the per-wave gradient partials unfolded (diagnostics: lets a caller time
                                 the adjoint kernel alone; grad_w1 / grad_b1 / grad_theta are then NOT updated) */
 
+#define HODE_FLAG_OVERWRITE_GRADS 2 /* backward: STORE grad_w1 / grad_b1 / grad_theta instead of accumulating into them (the
+                                      caller then need not zero them).  hode_rk_bwd with the ROCHE kinds only; HODE_E_UNSUPPORTED elsewhere */
+
 /* argument errors */
 #define HODE_E_NULL -1      /* a required pointer is NULL */
 #define HODE_E_SIZE -2      /* struct_size mismatch / non-positive dimension */

@@ -276,3 +276,32 @@ def test_split_layout_forward_vs_oracle(D, method):
     _compare(_run_hip(inp, f, method, 48, dev, cot=cot), _run_oracle(inp, f, method, cot=cot))
     inp, f = _case(40, 20, D, seed=91, n_dose=2)
     _compare(_run_hip(inp, f, method, 48, dev, cot=cot), _run_oracle(inp, f, method, cot=cot))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [4, 16, 48])
+def test_plan_overwrite_flag_matches_accumulating_backward(lanes):
+    """HODE_FLAG_OVERWRITE_GRADS (what RocheRKPlan sets): the fold STORES the parameter gradients -- same values as the
+    accumulate-into-zeroed-buffers path of roche_solve, and a second backward does not double them."""
+    dev = _dev()
+    from hode.plan import RocheRKPlan
+    from hode.solver import pack_theta
+    from oracle.rhs import THETA_NAMES
+    N, T, D = 130, 12, 12
+    inp, f = _case(N, T, D, seed=123)
+    cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(5))
+    ref = _run_hip(inp, f, "rk4", lanes, dev, cot=cot)
+    theta = pack_theta([getattr(f, n).detach().to(dev) for n in THETA_NAMES], dev)
+    dosage, times = dose_schedule(inp["actions"], f.step_size)
+    plan = RocheRKPlan(inp["z0"].to(dev), theta, f.ml_net[0].weight.detach().to(dev), f.ml_net[0].bias.detach().to(dev),
+                       inp["t"].to(dev), dosage.to(dev), times.to(dev), method="rk4", lanes_per_patient=lanes)
+    plan.grad_flat.fill_(7.0)  # stale contents must not leak into the result
+    plan.grad_h.copy_(cot.to(dev))
+    for _ in range(2):
+        plan.forward()
+        gy0, flat = plan.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.h.cpu(), ref["h"])
+    assert torch.equal(gy0.cpu(), ref["gy0"])
+    assert torch.equal(plan.grad_w.cpu(), ref["gw"]) and torch.equal(plan.grad_b.cpu(), ref["gb"])
+    assert torch.equal(plan.grad_theta[:13].cpu(), ref["gtheta"])
