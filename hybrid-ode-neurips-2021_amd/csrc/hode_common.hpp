@@ -53,6 +53,31 @@ HODE_DEV float tanh_precise_f32(float x) {
 // logistic sigmoid via tanh: sigma(x) = 0.5 + 0.5 tanh(x/2)
 HODE_DEV float sigmoid_f32(float x) { return __builtin_fmaf(tanh_f32(0.5f * x), 0.5f, 0.5f); }
 
+// ---------------------------------------------------------------------------------------------------------
+// packed fp32: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 retire TWO fp32 operations in the issue slot of one
+// (tools/micro/issue_rates.hip: 2.28 ns per wave-instruction for v_fma_f32 and for v_pk_fma_f32 alike, dependent or
+// not) -- the solver kernels are bound by issue slots, so the paired algebra is written with this type explicitly
+// (the SLP vectoriser's automatic pairing costs more v_mov than it saves and is switched off for these files).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+HODE_DEV f2 splat2(float x) { f2 r = {x, x}; return r; }
+HODE_DEV f2 pair2(float a, float b) { f2 r = {a, b}; return r; }
+HODE_DEV float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+HODE_DEV f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+HODE_DEV f2 vfma(float a, f2 b, f2 c) { return __builtin_elementwise_fma(splat2(a), b, c); }
+HODE_DEV f2 vfma(f2 a, float b, f2 c) { return __builtin_elementwise_fma(a, splat2(b), c); }
+template <class V> HODE_DEV V vsplat(float x);
+template <> HODE_DEV float vsplat<float>(float x) { return x; }
+template <> HODE_DEV f2 vsplat<f2>(float x) { return splat2(x); }
+HODE_DEV float hsum(f2 v) { return v.x + v.y; }
+HODE_DEV f2 tanh_f32(f2 x) {  // the two transcendentals stay scalar, the three arithmetic steps are packed
+  const f2 t = x * splat2(2.885390081777927f);
+  const f2 e = pair2(__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)) + splat2(1.0f);
+  return vfma(pair2(__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)), splat2(-2.0f), splat2(1.0f));
+}
+HODE_DEV bool vfinite(float v) { return __builtin_isfinite(v); }
+HODE_DEV bool vfinite(f2 v) { return __builtin_isfinite(v.x) && __builtin_isfinite(v.y); }
+
 // IEEE-correct-ish division (v_rcp + one Newton step; result within 1 ulp for normal operands)
 HODE_DEV float div_f32(float a, float b) {
   float r = __builtin_amdgcn_rcpf(b);

@@ -57,30 +57,89 @@ struct SpTimes {
 template <int METHOD>
 constexpr int sp_stages() { return METHOD == HODE_METHOD_EULER ? 1 : (METHOD == HODE_METHOD_MIDPOINT ? 2 : 4); }
 
-// stage state i (0-based) of the scheme from y and the earlier stage derivatives, one component
-template <int METHOD>
-HODE_DEV float sp_stage_state(int i, float y, float dt, float k1, float k2, float k3) {
+// stage state i (0-based) of the scheme from y and the earlier stage derivatives; V = float (one component) or f2 (a
+// packed pair of components, same operations in the same order: the results are identical)
+template <int METHOD, class V>
+HODE_DEV V sp_stage_state(int i, V y, float dt, V k1, V k2, V k3) {
   constexpr float c13 = (float)(1.0 / 3.0);
-  if constexpr (METHOD == HODE_METHOD_MIDPOINT) return i == 0 ? y : __builtin_fmaf(k1, 0.5f * dt, y);
+  if constexpr (METHOD == HODE_METHOD_MIDPOINT) return i == 0 ? y : vfma(k1, vsplat<V>(0.5f * dt), y);
   else if constexpr (METHOD == HODE_METHOD_RK4_38) {
     if (i == 0) return y;
-    if (i == 1) return __builtin_fmaf(dt * k1, c13, y);
-    if (i == 2) return __builtin_fmaf(dt, __builtin_fmaf(-k1, c13, k2), y);
-    return __builtin_fmaf(dt, (k1 - k2) + k3, y);
+    if (i == 1) return vfma(dt * k1, vsplat<V>(c13), y);
+    if (i == 2) return vfma(vsplat<V>(dt), vfma(-k1, vsplat<V>(c13), k2), y);
+    return vfma(vsplat<V>(dt), (k1 - k2) + k3, y);
   } else return y;
 }
-template <int METHOD>
-HODE_DEV float sp_advance(float y, float dt, float k1, float k2, float k3, float k4) {
-  if constexpr (METHOD == HODE_METHOD_EULER) return __builtin_fmaf(dt, k1, y);
-  else if constexpr (METHOD == HODE_METHOD_MIDPOINT) return __builtin_fmaf(dt, k2, y);
-  else return __builtin_fmaf((k1 + 3.0f * (k2 + k3)) + k4, dt * 0.125f, y);
+template <int METHOD, class V>
+HODE_DEV V sp_advance(V y, float dt, V k1, V k2, V k3, V k4) {
+  if constexpr (METHOD == HODE_METHOD_EULER) return vfma(vsplat<V>(dt), k1, y);
+  else if constexpr (METHOD == HODE_METHOD_MIDPOINT) return vfma(vsplat<V>(dt), k2, y);
+  else return vfma((k1 + 3.0f * (k2 + k3)) + k4, vsplat<V>(dt * 0.125f), y);
 }
+
+template <int MR> struct OwnSel { typedef float type; };
+template <> struct OwnSel<2> { typedef f2 type; };
+
+// The learned block as one lane of a patient's DPP quad sees it: MR = (D-4)/4 rows of tanh(W y + b), the weights held as
+// (even column, odd column) pairs so that a row is D/2 v_pk_fma_f32 -- lane .x sums the even columns starting from the
+// bias, lane .y the odd ones, one add joins them (the same two partial sums the scalar kernels form).
+template <int D>
+struct MlRows {
+  static constexpr int M = D - 4, MR = M / 4, DP = D / 2, MP = M / 2;
+  typedef typename OwnSel<MR>::type Own;
+  f2 wp[MR][DP];
+  float bias[MR];
+  HODE_DEV void load(const float* __restrict__ W, const float* __restrict__ b, int q) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+      const int rowi = q * MR + r;
+#pragma unroll
+      for (int ip = 0; ip < DP; ++ip) wp[r][ip] = pair2(W[rowi * D + 2 * ip], W[rowi * D + 2 * ip + 1]);
+      bias[r] = b[rowi];
+    }
+  }
+  // all-gather of the quad's own components into the pairs Y2[2..DP) (component 4 + j lives in lane j / MR)
+  static HODE_DEV void gather(Own v, f2* __restrict__ out) {
+    if constexpr (MR == 2) {
+      out[0] = pair2(quad_bcast<0>(v.x), quad_bcast<0>(v.y));
+      out[1] = pair2(quad_bcast<1>(v.x), quad_bcast<1>(v.y));
+      out[2] = pair2(quad_bcast<2>(v.x), quad_bcast<2>(v.y));
+      out[3] = pair2(quad_bcast<3>(v.x), quad_bcast<3>(v.y));
+    } else {
+      out[0] = pair2(quad_bcast<0>(v), quad_bcast<1>(v));
+      out[1] = pair2(quad_bcast<2>(v), quad_bcast<3>(v));
+    }
+  }
+  HODE_DEV Own rhs(const f2 (&Y2)[DP]) const {
+    float z[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+      f2 acc = pair2(bias[r], 0.f);
+#pragma unroll
+      for (int ip = 0; ip < DP; ++ip) acc = vfma(wp[r][ip], Y2[ip], acc);
+      z[r] = hsum(acc);
+    }
+    if constexpr (MR == 2) return tanh_f32(pair2(z[0], z[1]));
+    else return tanh_f32(z[0]);
+  }
+  static HODE_DEV Own load_own(const float* __restrict__ src, int q) {
+    if constexpr (MR == 2) {
+      const float2 x = *reinterpret_cast<const float2*>(src + 4 + 2 * q);
+      return pair2(x.x, x.y);
+    } else return src[4 + q];
+  }
+  static HODE_DEV void store_own(float* __restrict__ dst, int q, Own v) {
+    if constexpr (MR == 2) *reinterpret_cast<float2*>(dst + 4 + 2 * q) = make_float2(v.x, v.y);
+    else dst[4 + q] = v;
+  }
+};
 
 template <int D, int METHOD, bool ABLATE, bool HILL2, bool K1>
 HODE_DEV void split_fwd_body(const SplitArgs& a) {
   constexpr int NS = sp_stages<METHOD>();
-  constexpr int M = D - 4;
-  constexpr int MR = M / 4;
+  typedef MlRows<D> Ml;
+  typedef typename Ml::Own Own;
+  constexpr int DP = Ml::DP;
   __shared__ __attribute__((aligned(16))) float ring[2][4][kSplitPatients][4];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -100,32 +159,39 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     ds.tau0 = K1 ? ds.taus[0] : 0.f;
     MlSlice<4, 1> none;
     float own1[1];
-    float y[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = a.y0[(size_t)p * D + i];
-    if (live) *reinterpret_cast<float4*>(a.h + (size_t)p * D) = make_float4(y[0], y[1], y[2], y[3]);
+    // the state as two packed pairs (Disease, ImmuneReact), (Immunity, Dose2): the stage algebra is 2 instructions wide
+    f2 ya, yb;
+    {
+      const float4 v = *reinterpret_cast<const float4*>(a.y0 + (size_t)p * D);
+      ya = pair2(v.x, v.y);
+      yb = pair2(v.z, v.w);
+      if (live) *reinterpret_cast<float4*>(a.h + (size_t)p * D) = v;
+    }
     for (int it = 0; it < a.T; ++it) {
       if (it + 1 < a.T) {
         const SpTimes st(a.t, it, a.perturb, METHOD);
-        float k[4][4] = {};
-        float Y[4];
+        f2 ka[4], kb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ka[s] = kb[s] = splat2(0.f);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) Y[c] = sp_stage_state<METHOD>(s, y[c], st.dt, k[0][c], k[1][c], k[2][c]);
-          if (slot < kSplitPatients) *reinterpret_cast<float4*>(&ring[it & 1][s][slot][0]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
-          roche_rhs<4, 1, ABLATE, HILL2>(th, none, ds.at(st.ts[s], th.kel).v, Y, k[s], own1);
+          const f2 Ya = sp_stage_state<METHOD>(s, ya, st.dt, ka[0], ka[1], ka[2]);
+          const f2 Yb = sp_stage_state<METHOD>(s, yb, st.dt, kb[0], kb[1], kb[2]);
+          if (slot < kSplitPatients) *reinterpret_cast<float4*>(&ring[it & 1][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
+          const float Y[4] = {Ya.x, Ya.y, Yb.x, Yb.y};
+          float k[4];
+          roche_rhs<4, 1, ABLATE, HILL2>(th, none, ds.at(st.ts[s], th.kel).v, Y, k, own1);
+          ka[s] = pair2(k[0], k[1]);
+          kb[s] = pair2(k[2], k[3]);
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = sp_advance<METHOD>(y[c], st.dt, k[0][c], k[1][c], k[2][c], k[3][c]);
-        if (live) *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + (size_t)p * D) = make_float4(y[0], y[1], y[2], y[3]);
+        ya = sp_advance<METHOD>(ya, st.dt, ka[0], ka[1], ka[2], ka[3]);
+        yb = sp_advance<METHOD>(yb, st.dt, kb[0], kb[1], kb[2], kb[3]);
+        if (live) *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + (size_t)p * D) = make_float4(ya.x, ya.y, yb.x, yb.y);
       }
       __syncthreads();
     }
     if (a.status) {
-      bool bad = false;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bad |= !__builtin_isfinite(y[c]);
+      const bool bad = !(vfinite(ya) && vfinite(yb));
       if (bad && live) atomicOr(a.status, HODE_STATUS_NONFINITE);
     }
   } else {
@@ -134,62 +200,33 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     const int slot = (wave - 1) * 16 + (lane >> 2);
     const bool live = b0 + slot < a.B;
     const int p = min(b0 + slot, a.B - 1);
-    float w[MR][D], bias[MR], yo[MR];
-#pragma unroll
-    for (int r = 0; r < MR; ++r) {
-      const int rowi = q * MR + r;
-#pragma unroll
-      for (int i = 0; i < D; ++i) w[r][i] = a.w1[rowi * D + i];
-      bias[r] = a.b1[rowi];
-      yo[r] = a.y0[(size_t)p * D + 4 + rowi];
-    }
-    auto store_own = [&](float* dst) {
-      if (!live) return;
-      if constexpr (MR == 2) *reinterpret_cast<float2*>(dst + 4 + 2 * q) = make_float2(yo[0], yo[1]);
-      else dst[4 + q] = yo[0];
-    };
-    store_own(a.h + (size_t)p * D);
+    Ml ml;
+    ml.load(a.w1, a.b1, q);
+    Own yo = Ml::load_own(a.y0 + (size_t)p * D, q);
+    if (live) Ml::store_own(a.h + (size_t)p * D, q, yo);
     __syncthreads();  // iteration 0: the expert wave fills ring[0]
     for (int it = 1; it < a.T; ++it) {
       const int n = it - 1;
       const float dt = a.t[n + 1] - a.t[n];
-      float k[4][MR] = {};
+      Own k[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) k[s] = vsplat<Own>(0.f);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        float Yo[MR], Y[D];
-#pragma unroll
-        for (int r = 0; r < MR; ++r) Yo[r] = sp_stage_state<METHOD>(s, yo[r], dt, k[0][r], k[1][r], k[2][r]);
+        const Own Yo = sp_stage_state<METHOD>(s, yo, dt, k[0], k[1], k[2]);
         const float4 e = *reinterpret_cast<const float4*>(&ring[n & 1][s][slot][0]);
-        Y[0] = e.x; Y[1] = e.y; Y[2] = e.z; Y[3] = e.w;
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-          Y[4 + 0 * MR + r] = quad_bcast<0>(Yo[r]);
-          Y[4 + 1 * MR + r] = quad_bcast<1>(Yo[r]);
-          Y[4 + 2 * MR + r] = quad_bcast<2>(Yo[r]);
-          Y[4 + 3 * MR + r] = quad_bcast<3>(Yo[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-          // two partial sums per row: shorter dependent fma chains
-          float z0 = bias[r], z1 = 0.f;
-#pragma unroll
-          for (int i = 0; i < D; i += 2) {
-            z0 = __builtin_fmaf(w[r][i], Y[i], z0);
-            z1 = __builtin_fmaf(w[r][i + 1], Y[i + 1], z1);
-          }
-          k[s][r] = tanh_f32(z0 + z1);
-        }
+        f2 Y2[DP];
+        Y2[0] = pair2(e.x, e.y);
+        Y2[1] = pair2(e.z, e.w);
+        Ml::gather(Yo, Y2 + 2);
+        k[s] = ml.rhs(Y2);
       }
-#pragma unroll
-      for (int r = 0; r < MR; ++r) yo[r] = sp_advance<METHOD>(yo[r], dt, k[0][r], k[1][r], k[2][r], k[3][r]);
-      store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D);
+      yo = sp_advance<METHOD>(yo, dt, k[0], k[1], k[2], k[3]);
+      if (live) Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
       __syncthreads();
     }
     if (a.status) {
-      bool bad = false;
-#pragma unroll
-      for (int r = 0; r < MR; ++r) bad |= !__builtin_isfinite(yo[r]);
-      if (bad && live) atomicOr(a.status, HODE_STATUS_NONFINITE);
+      if (!vfinite(yo) && live) atomicOr(a.status, HODE_STATUS_NONFINITE);
     }
   }
 }
@@ -218,12 +255,51 @@ struct SplitBwdArgs {
   int B, T, K, perturb;
 };
 
+// The cotangent algebra of one step of the scheme, shared by the expert wave (V = f2, two pairs) and the learned waves
+// (V = Own).  vjp(s, g) must return (df/dY)^T g at stage s.  lam is updated in place.
+template <int METHOD, class V, class F>
+HODE_DEV void sp_adjoint_step(V& lam, float dt, F&& vjp) {
+  constexpr float c13 = (float)(1.0 / 3.0);
+  if constexpr (METHOD == HODE_METHOD_EULER) {
+    lam += vjp(0, dt * lam);
+  } else if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
+    const V a1 = vjp(1, dt * lam);
+    lam += a1;
+    lam += vjp(0, (0.5f * dt) * a1);
+  } else {
+    const float w1 = dt * 0.125f, w3 = dt * 0.375f;
+    const V a3 = vjp(3, w1 * lam);
+    V da = dt * a3;
+    V g1 = vfma(w1, lam, da);
+    V g2 = vfma(w3, lam, -da);
+    const V g = vfma(w3, lam, da);
+    lam += a3;
+    const V a2 = vjp(2, g);
+    da = dt * a2;
+    g2 += da;
+    g1 = vfma(-c13, da, g1);
+    lam += a2;
+    const V a1 = vjp(1, g2);
+    g1 = vfma(c13, dt * a1, g1);
+    lam += a1;
+    lam += vjp(0, g1);
+  }
+}
+
+struct F4 {  // the expert wave's 4 components as two packed pairs
+  f2 a, b;
+  HODE_DEV F4& operator+=(const F4& o) { a += o.a; b += o.b; return *this; }
+  HODE_DEV F4 operator-() const { return F4{-a, -b}; }
+};
+HODE_DEV F4 operator*(float s, const F4& v) { return F4{s * v.a, s * v.b}; }
+HODE_DEV F4 vfma(float s, const F4& x, const F4& y) { return F4{vfma(s, x.a, y.a), vfma(s, x.b, y.b)}; }
+
 template <int D, int METHOD, bool ABLATE, bool HILL2, bool NEED_TH, bool K1>
 HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   constexpr int NS = sp_stages<METHOD>();
-  constexpr int M = D - 4;
-  constexpr int MR = M / 4;
-  constexpr float c13 = (float)(1.0 / 3.0);
+  typedef MlRows<D> Ml;
+  typedef typename Ml::Own Own;
+  constexpr int M = Ml::M, MR = Ml::MR, DP = Ml::DP, MP = Ml::MP;
   __shared__ __attribute__((aligned(16))) float yring[2][4][kSplitPatients][4];   // expert stage states
   __shared__ __attribute__((aligned(16))) float cring[2][4][kSplitPatients][4];   // learned block -> expert cotangent
   __shared__ __attribute__((aligned(16))) float dring[2][4][kSplitPatients][2];   // Dose(t_s), dDose/dkel
@@ -256,26 +332,35 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     // (a): stage states + doses of step m into ring buffer `par`
     auto recompute = [&](int m, int par) {
       const SpTimes st(a.t, m, a.perturb, METHOD);
-      float y[4], k[4][4] = {}, Y[4];
       const float4 hv = *reinterpret_cast<const float4*>(a.h + (size_t)m * row + (size_t)p * D);
-      y[0] = hv.x; y[1] = hv.y; y[2] = hv.z; y[3] = hv.w;
+      const f2 ya = pair2(hv.x, hv.y), yb = pair2(hv.z, hv.w);
+      f2 ka[4], kb[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ka[s] = kb[s] = splat2(0.f);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Y[c] = sp_stage_state<METHOD>(s, y[c], st.dt, k[0][c], k[1][c], k[2][c]);
+        const f2 Ya = sp_stage_state<METHOD>(s, ya, st.dt, ka[0], ka[1], ka[2]);
+        const f2 Yb = sp_stage_state<METHOD>(s, yb, st.dt, kb[0], kb[1], kb[2]);
         const DoseVal dv = ds.at(st.ts[s], th.kel);
         if (mine) {
-          *reinterpret_cast<float4*>(&yring[par][s][slot][0]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
+          *reinterpret_cast<float4*>(&yring[par][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
           *reinterpret_cast<float2*>(&dring[par][s][slot][0]) = make_float2(dv.v, dv.dk);
         }
-        if (s + 1 < NS) roche_rhs<4, 1, ABLATE, HILL2>(th, none, dv.v, Y, k[s], own1);
+        if (s + 1 < NS) {
+          const float Y[4] = {Ya.x, Ya.y, Yb.x, Yb.y};
+          float k[4];
+          roche_rhs<4, 1, ABLATE, HILL2>(th, none, dv.v, Y, k, own1);
+          ka[s] = pair2(k[0], k[1]);
+          kb[s] = pair2(k[2], k[3]);
+        }
       }
     };
 
-    float lam[4];
+    F4 lam;
     {
       const float4 g4 = *reinterpret_cast<const float4*>(a.grad_h + (size_t)(T - 1) * row + (size_t)p * D);
-      lam[0] = lv * g4.x; lam[1] = lv * g4.y; lam[2] = lv * g4.z; lam[3] = lv * g4.w;
+      lam.a = lv * pair2(g4.x, g4.y);
+      lam.b = lv * pair2(g4.z, g4.w);
     }
     if (T >= 2) recompute(T - 2, 0);
     __syncthreads();
@@ -285,7 +370,8 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         const int m = T - 1 - k;
         const int par = (k - 1) & 1;
         const float dt = a.t[m + 1] - a.t[m];
-        float Y[4][4], cs[4][4];
+        float Y[4][4];
+        F4 cs[4];
         DoseVal dv[4];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -293,77 +379,28 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
           const float4 cv = *reinterpret_cast<const float4*>(&cring[par][s][slot][0]);
           const float2 d2 = *reinterpret_cast<const float2*>(&dring[par][s][slot][0]);
           Y[s][0] = yv.x; Y[s][1] = yv.y; Y[s][2] = yv.z; Y[s][3] = yv.w;
-          cs[s][0] = lv * cv.x; cs[s][1] = lv * cv.y; cs[s][2] = lv * cv.z; cs[s][3] = lv * cv.w;
+          cs[s].a = lv * pair2(cv.x, cv.y);
+          cs[s].b = lv * pair2(cv.z, cv.w);
           dv[s].v = d2.x; dv[s].dk = d2.y;
         }
-        float g[4], av[4];
-        auto vjp = [&](int s, const float (&gs)[4]) {
-          roche_vjp<4, 1, ABLATE, HILL2, NEED_TH>(th, none, nonec, ln_ec50, dv[s], Y[s], own1, gs, 0, av, acc);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) av[c] += cs[s][c];
-        };
-        if constexpr (METHOD == HODE_METHOD_EULER) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) g[c] = dt * lam[c];
-          vjp(0, g);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) lam[c] += av[c];
-        } else if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
-          const float half = 0.5f * dt;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) g[c] = dt * lam[c];
-          vjp(1, g);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            lam[c] += av[c];
-            g[c] = half * av[c];
-          }
-          vjp(0, g);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) lam[c] += av[c];
-        } else {
-          const float w1 = dt * 0.125f, w3 = dt * 0.375f;
-          float g1[4], g2[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) g[c] = w1 * lam[c];
-          vjp(3, g);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float da = dt * av[c];
-            g1[c] = __builtin_fmaf(w1, lam[c], da);
-            g2[c] = __builtin_fmaf(w3, lam[c], -da);
-            g[c] = __builtin_fmaf(w3, lam[c], da);
-            lam[c] += av[c];
-          }
-          vjp(2, g);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float da = dt * av[c];
-            g2[c] += da;
-            g1[c] = __builtin_fmaf(-c13, da, g1[c]);
-            lam[c] += av[c];
-          }
-          vjp(1, g2);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            g1[c] = __builtin_fmaf(c13, dt * av[c], g1[c]);
-            lam[c] += av[c];
-          }
-          vjp(0, g1);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) lam[c] += av[c];
-        }
+        sp_adjoint_step<METHOD>(lam, dt, [&](int s, const F4& gs) {
+          const float g[4] = {gs.a.x, gs.a.y, gs.b.x, gs.b.y};
+          float av[4];
+          roche_vjp<4, 1, ABLATE, HILL2, NEED_TH>(th, none, nonec, ln_ec50, dv[s], Y[s], own1, g, 0, av, acc);
+          F4 r = cs[s];
+          r.a += pair2(av[0], av[1]);
+          r.b += pair2(av[2], av[3]);
+          return r;
+        });
         const float4 g4 = *reinterpret_cast<const float4*>(a.grad_h + (size_t)m * row + (size_t)p * D);
-        lam[0] = __builtin_fmaf(lv, g4.x, lam[0]);
-        lam[1] = __builtin_fmaf(lv, g4.y, lam[1]);
-        lam[2] = __builtin_fmaf(lv, g4.z, lam[2]);
-        lam[3] = __builtin_fmaf(lv, g4.w, lam[3]);
+        lam.a = vfma(lv, pair2(g4.x, g4.y), lam.a);
+        lam.b = vfma(lv, pair2(g4.z, g4.w), lam.b);
       }
       // ---- (a) stage states of step T-3-k for the learned waves' next iteration
       if (T - 3 - k >= 0) recompute(T - 3 - k, (k + 1) & 1);
       __syncthreads();
     }
-    if (live) *reinterpret_cast<float4*>(a.grad_y0 + (size_t)p * D) = make_float4(lam[0], lam[1], lam[2], lam[3]);
+    if (live) *reinterpret_cast<float4*>(a.grad_y0 + (size_t)p * D) = make_float4(lam.a.x, lam.a.y, lam.b.x, lam.b.y);
 #pragma unroll
     for (int i = 0; i < kNTheta; ++i) {
       const float v = wave_sum(NEED_TH ? acc.dth[i] : 0.f);
@@ -376,41 +413,35 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     const bool live = b0 + slot < a.B;
     const int p = min(b0 + slot, a.B - 1);
     const float lv = live ? 1.0f : 0.0f;
-    float w[MR][D], bias[MR], wt[M][MR], wc[M], dw[MR][D], db[MR];
+    Ml ml;
+    ml.load(a.w1, a.b1, q);
+    // transposed operands of a = W^T u.  wc2: column q of W (the expert component this lane reports to the expert wave),
+    // paired over the rows j;  MR == 2: wtp[j] = (W[j][own0], W[j][own1]) (row-paired, the result is the Own pair);
+    // MR == 1: wt2[jp] = (W[2jp][own], W[2jp+1][own]).
+    f2 wc2[MP], wtp[MR == 2 ? M : MP];
 #pragma unroll
-    for (int r = 0; r < MR; ++r) {
-      const int rowi = q * MR + r;
+    for (int jp = 0; jp < MP; ++jp) wc2[jp] = pair2(a.w1[(2 * jp) * D + q], a.w1[(2 * jp + 1) * D + q]);
+    if constexpr (MR == 2) {
 #pragma unroll
-      for (int i = 0; i < D; ++i) {
-        w[r][i] = a.w1[rowi * D + i];
-        dw[r][i] = 0.f;
-      }
-      bias[r] = a.b1[rowi];
-      db[r] = 0.f;
+      for (int j = 0; j < M; ++j) wtp[j] = pair2(a.w1[j * D + 4 + 2 * q], a.w1[j * D + 4 + 2 * q + 1]);
+    } else {
+#pragma unroll
+      for (int jp = 0; jp < MP; ++jp) wtp[jp] = pair2(a.w1[(2 * jp) * D + 4 + q], a.w1[(2 * jp + 1) * D + 4 + q]);
     }
+    f2 dw2[MR][DP];
+    Own db = vsplat<Own>(0.f);
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
-      wc[j] = a.w1[j * D + q];
+    for (int r = 0; r < MR; ++r)
 #pragma unroll
-      for (int r = 0; r < MR; ++r) wt[j][r] = a.w1[j * D + 4 + q * MR + r];
-    }
-    auto load_own = [&](const float* src, float (&v)[MR]) {
-      if constexpr (MR == 2) {
-        const float2 x = *reinterpret_cast<const float2*>(src + 4 + 2 * q);
-        v[0] = x.x; v[1] = x.y;
-      } else v[0] = src[4 + q];
-    };
-    float lam[MR];
-    load_own(a.grad_h + (size_t)(T - 1) * row + (size_t)p * D, lam);
-#pragma unroll
-    for (int r = 0; r < MR; ++r) lam[r] *= lv;
+      for (int ip = 0; ip < DP; ++ip) dw2[r][ip] = splat2(0.f);
+    Own lam = lv * Ml::load_own(a.grad_h + (size_t)(T - 1) * row + (size_t)p * D, q);
     // the operands of iteration k+1 are fetched during iteration k (the state is needed by the very first instruction of
     // an iteration: an un-hidden HBM round trip would cost a quarter of it)
-    float yo_nx[MR] = {}, gh_nx[MR] = {};
+    Own yo_nx, gh_nx;
     {
       const int m0 = T >= 2 ? T - 2 : 0;
-      load_own(a.h + (size_t)m0 * row + (size_t)p * D, yo_nx);
-      load_own(a.grad_h + (size_t)m0 * row + (size_t)p * D, gh_nx);
+      yo_nx = Ml::load_own(a.h + (size_t)m0 * row + (size_t)p * D, q);
+      gh_nx = Ml::load_own(a.grad_h + (size_t)m0 * row + (size_t)p * D, q);
     }
     __syncthreads();  // the expert wave's prologue fills ring 0
     for (int k = 0; k < T; ++k) {
@@ -418,140 +449,78 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         const int m = T - 2 - k;
         const int par = k & 1;
         const float dt = a.t[m + 1] - a.t[m];
-        float yo[MR], gh[MR];
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-          yo[r] = yo_nx[r];
-          gh[r] = gh_nx[r];
-        }
+        const Own yo = yo_nx, gh = gh_nx;
         {
           const int mn = m >= 1 ? m - 1 : 0;  // clamped: the last prefetch is simply unused
-          load_own(a.h + (size_t)mn * row + (size_t)p * D, yo_nx);
-          load_own(a.grad_h + (size_t)mn * row + (size_t)p * D, gh_nx);
+          yo_nx = Ml::load_own(a.h + (size_t)mn * row + (size_t)p * D, q);
+          gh_nx = Ml::load_own(a.grad_h + (size_t)mn * row + (size_t)p * D, q);
         }
         // ---- recompute the learned stage derivatives
-        float Y[4][D], so[4][MR] = {};
+        f2 Y2[4][DP];
+        Own so[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) so[s] = vsplat<Own>(0.f);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          float Yo[MR];
-#pragma unroll
-          for (int r = 0; r < MR; ++r) Yo[r] = sp_stage_state<METHOD>(s, yo[r], dt, so[0][r], so[1][r], so[2][r]);
+          const Own Yo = sp_stage_state<METHOD>(s, yo, dt, so[0], so[1], so[2]);
           const float4 e = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
-          Y[s][0] = e.x; Y[s][1] = e.y; Y[s][2] = e.z; Y[s][3] = e.w;
-#pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            Y[s][4 + 0 * MR + r] = quad_bcast<0>(Yo[r]);
-            Y[s][4 + 1 * MR + r] = quad_bcast<1>(Yo[r]);
-            Y[s][4 + 2 * MR + r] = quad_bcast<2>(Yo[r]);
-            Y[s][4 + 3 * MR + r] = quad_bcast<3>(Yo[r]);
-          }
-#pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            float z0 = bias[r], z1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < D; i += 2) {
-              z0 = __builtin_fmaf(w[r][i], Y[s][i], z0);
-              z1 = __builtin_fmaf(w[r][i + 1], Y[s][i + 1], z1);
-            }
-            so[s][r] = tanh_f32(z0 + z1);
-          }
+          Y2[s][0] = pair2(e.x, e.y);
+          Y2[s][1] = pair2(e.z, e.w);
+          Ml::gather(Yo, Y2[s] + 2);
+          so[s] = ml.rhs(Y2[s]);
         }
         // ---- adjoint of the stages
-        float g[MR], av[MR];
-        auto vjp = [&](int s, const float (&gs)[MR]) {
-          float u[MR], uf[M];
+        sp_adjoint_step<METHOD>(lam, dt, [&](int s, Own gs) {
+          const Own u = gs * vfma(-so[s], so[s], vsplat<Own>(1.0f));
+          db += u;
+          f2 uf2[MP];
+          Ml::gather(u, uf2);
+          if constexpr (MR == 2) {
 #pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            u[r] = gs[r] * __builtin_fmaf(-so[s][r], so[s][r], 1.0f);
-            db[r] += u[r];
+            for (int ip = 0; ip < DP; ++ip) {
+              dw2[0][ip] = vfma(u.x, Y2[s][ip], dw2[0][ip]);
+              dw2[1][ip] = vfma(u.y, Y2[s][ip], dw2[1][ip]);
+            }
+          } else {
 #pragma unroll
-            for (int i = 0; i < D; ++i) dw[r][i] = __builtin_fmaf(u[r], Y[s][i], dw[r][i]);
-            uf[0 * MR + r] = quad_bcast<0>(u[r]);
-            uf[1 * MR + r] = quad_bcast<1>(u[r]);
-            uf[2 * MR + r] = quad_bcast<2>(u[r]);
-            uf[3 * MR + r] = quad_bcast<3>(u[r]);
+            for (int ip = 0; ip < DP; ++ip) dw2[0][ip] = vfma(u, Y2[s][ip], dw2[0][ip]);
           }
-          float cq = 0.f;
+          f2 c2 = splat2(0.f);
 #pragma unroll
-          for (int r = 0; r < MR; ++r) av[r] = 0.f;
+          for (int jp = 0; jp < MP; ++jp) c2 = vfma(wc2[jp], uf2[jp], c2);
+          cring[par][s][slot][q] = hsum(c2);
+          if constexpr (MR == 2) {
+            f2 av = splat2(0.f);
 #pragma unroll
-          for (int j = 0; j < M; ++j) {
-            cq = __builtin_fmaf(wc[j], uf[j], cq);
+            for (int jp = 0; jp < MP; ++jp) {
+              av = vfma(wtp[2 * jp], uf2[jp].x, av);
+              av = vfma(wtp[2 * jp + 1], uf2[jp].y, av);
+            }
+            return av;
+          } else {
+            f2 a2 = splat2(0.f);
 #pragma unroll
-            for (int r = 0; r < MR; ++r) av[r] = __builtin_fmaf(wt[j][r], uf[j], av[r]);
+            for (int jp = 0; jp < MP; ++jp) a2 = vfma(wtp[jp], uf2[jp], a2);
+            return hsum(a2);
           }
-          cring[par][s][slot][q] = cq;
-        };
-        if constexpr (METHOD == HODE_METHOD_EULER) {
-#pragma unroll
-          for (int r = 0; r < MR; ++r) g[r] = dt * lam[r];
-          vjp(0, g);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) lam[r] += av[r];
-        } else if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
-          const float half = 0.5f * dt;
-#pragma unroll
-          for (int r = 0; r < MR; ++r) g[r] = dt * lam[r];
-          vjp(1, g);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            lam[r] += av[r];
-            g[r] = half * av[r];
-          }
-          vjp(0, g);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) lam[r] += av[r];
-        } else {
-          const float w1 = dt * 0.125f, w3 = dt * 0.375f;
-          float g1[MR], g2[MR];
-#pragma unroll
-          for (int r = 0; r < MR; ++r) g[r] = w1 * lam[r];
-          vjp(3, g);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            const float da = dt * av[r];
-            g1[r] = __builtin_fmaf(w1, lam[r], da);
-            g2[r] = __builtin_fmaf(w3, lam[r], -da);
-            g[r] = __builtin_fmaf(w3, lam[r], da);
-            lam[r] += av[r];
-          }
-          vjp(2, g);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            const float da = dt * av[r];
-            g2[r] += da;
-            g1[r] = __builtin_fmaf(-c13, da, g1[r]);
-            lam[r] += av[r];
-          }
-          vjp(1, g2);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) {
-            g1[r] = __builtin_fmaf(c13, dt * av[r], g1[r]);
-            lam[r] += av[r];
-          }
-          vjp(0, g1);
-#pragma unroll
-          for (int r = 0; r < MR; ++r) lam[r] += av[r];
-        }
-#pragma unroll
-        for (int r = 0; r < MR; ++r) lam[r] = __builtin_fmaf(lv, gh[r], lam[r]);
+        });
+        lam = vfma(lv, gh, lam);
       }
       __syncthreads();
     }
-    if (live) {
-      float* dst = a.grad_y0 + (size_t)p * D;
-      if constexpr (MR == 2) *reinterpret_cast<float2*>(dst + 4 + 2 * q) = make_float2(lam[0], lam[1]);
-      else dst[4 + q] = lam[0];
-    }
+    if (live) Ml::store_own(a.grad_y0 + (size_t)p * D, q, lam);
     float* out = a.part_ml + ((size_t)blockIdx.x * 3 + (wave - 1)) * (M * D + M);
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        const float v = wave_sum_stride4(dw[r][i]);
+        const float v = wave_sum_stride4((i & 1) ? dw2[r][i / 2].y : dw2[r][i / 2].x);
         if (lane < 4) out[(lane * MR + r) * D + i] = v;
       }
-      const float vb = wave_sum_stride4(db[r]);
+      float dbr;
+      if constexpr (MR == 2) dbr = r == 0 ? db.x : db.y;
+      else dbr = db;
+      const float vb = wave_sum_stride4(dbr);
       if (lane < 4) out[M * D + lane * MR + r] = vb;
     }
   }
