@@ -51,7 +51,7 @@ def log(msg):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 
-def build_plan(dev, rank, lanes=0, need_theta=True):
+def build_plan(dev, rank, lanes=0, need_theta=True, tape=True):
     from hode import synth
     from hode.plan import RocheRKPlan
     from hode.solver import pack_theta
@@ -62,7 +62,7 @@ def build_plan(dev, rank, lanes=0, need_theta=True):
     dosage = chan.max(dim=0)[0]
     times = (torch.nonzero((chan != 0).t())[:, 1].reshape(N_PER_GPU, -1) * synth.STEP).float()
     plan = RocheRKPlan(inp["z0"].to(dev), theta.to(dev), w.to(dev), b.to(dev), inp["t"].to(dev), dosage.to(dev),
-                       times.to(dev), method="rk4", lanes_per_patient=lanes, need_theta_grad=need_theta)
+                       times.to(dev), method="rk4", lanes_per_patient=lanes, need_theta_grad=need_theta, tape=tape)
     gen = torch.Generator().manual_seed(99 + rank)
     plan.grad_h.copy_(torch.randn(T, N_PER_GPU, D, generator=gen))  # synthetic cotangent (what the readout+loss would send)
     return plan, inp, (w, b)
@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--lanes", type=int, default=0, help="force lanes per patient (1|4), 0 = library default")
     ap.add_argument("--no-theta-grad", action="store_true", help="skip the 13 expert-constant gradients")
+    ap.add_argument("--no-tape", action="store_true", help="backward re-integrates the expert stages instead of reading the forward's tape")
     ap.add_argument("--full-step", action="store_true", help="also time one full training step (encoder + loss) as an extra field")
     args = ap.parse_args()
 
@@ -198,7 +199,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
 
-    plan, inp, wb = build_plan(dev, rank, lanes=args.lanes, need_theta=not args.no_theta_grad)
+    plan, inp, wb = build_plan(dev, rank, lanes=args.lanes, need_theta=not args.no_theta_grad, tape=not args.no_tape)
     use_graph = not args.no_graph
     log("rank %d: plan built (B=%d, T=%d, D=%d)" % (rank, N_PER_GPU, T, D))
     if use_graph:

@@ -193,7 +193,8 @@ extern "C" size_t hode_workspace_bytes(const hode_solve_desc* d, int which) {
   if (d->rhs_kind == HODE_RHS_ROCHE_REAL && (which == HODE_WS_RK_FWD || which == HODE_WS_RK_BWD))
     return hode::real_workspace_bytes(d, which == HODE_WS_RK_BWD);
   switch (which) {
-    case HODE_WS_RK_FWD: return 0;
+    case HODE_WS_RK_FWD:  // only the split layout's tape (HODE_FLAG_TAPE): the buffer hode_rk_bwd will be handed again
+      return ((d->flags & HODE_FLAG_TAPE) && use_split(d, false) && use_split(d, true)) ? hode::split_workspace_bytes(d) : 0;
     case HODE_WS_RK_BWD:
       if (use_split(d, true)) return hode::split_workspace_bytes(d);
       if (use_mf(d)) return hode::mf_workspace_bytes(d);
@@ -210,6 +211,9 @@ extern "C" int hode_rk_fwd(const hode_solve_desc* d, void* stream) {
   if (d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_ROCHE_REAL)
     return hode::real_rk(d, false, (hipStream_t)stream);
   if (int e = check_rk(d, false)) return e;
+  const size_t need = hode_workspace_bytes(d, HODE_WS_RK_FWD);
+  if (need && (!d->workspace || d->workspace_bytes < need))
+    return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B (HODE_FLAG_TAPE)", d->workspace_bytes, need);
   return dispatch_dim(d, false, (hipStream_t)stream);
 }
 

@@ -32,6 +32,7 @@ struct SplitArgs {
   const float* __restrict__ w1;
   const float* __restrict__ b1;
   float* __restrict__ h;
+  float* __restrict__ tape;  // TAPE: [T-1][NS-1][B][4] expert stage states 1..NS-1 of every step (stage 0 is h itself)
   int* __restrict__ status;
   int B, T, K, perturb;
 };
@@ -53,6 +54,22 @@ struct SpTimes {
     }
   }
 };
+
+// The time of stage q (0..3) of the step [t0, t1] exactly as SpTimes forms it, for a lane that needs only its own stage (the learned
+// waves evaluate the dose schedule with one stage per quad lane).  t0 + dt * 0 is t0 exactly, so only q == 3 selects.
+template <int METHOD>
+HODE_DEV float sp_stage_time(float t0, float t1, int perturb, int q) {
+  const float dt = t1 - t0;
+  const float c = METHOD == HODE_METHOD_RK4_38 ? (q == 1 ? (float)(1.0 / 3.0) : (q == 2 ? (float)(2.0 / 3.0) : 0.f))
+                                               : (q == 0 ? 0.f : 0.5f);
+  float tq = add_rn(t0, mul_rn(dt, c));
+  tq = q == 3 ? t1 : tq;
+  if (perturb) {
+    if (q == 0) tq = nextafter_up(t0);
+    if (q == 3) tq = nextafter_down(t1);
+  }
+  return tq;
+}
 
 template <int METHOD>
 constexpr int sp_stages() { return METHOD == HODE_METHOD_EULER ? 1 : (METHOD == HODE_METHOD_MIDPOINT ? 2 : 4); }
@@ -80,47 +97,99 @@ HODE_DEV V sp_advance(V y, float dt, V k1, V k2, V k3, V k4) {
 template <int MR> struct OwnSel { typedef float type; };
 template <> struct OwnSel<2> { typedef f2 type; };
 
-// The learned block as one lane of a patient's DPP quad sees it: MR = (D-4)/4 rows of tanh(W y + b), the weights held as
-// (even column, odd column) pairs so that a row is D/2 v_pk_fma_f32 -- lane .x sums the even columns starting from the
-// bias, lane .y the odd ones, one add joins them (the same two partial sums the scalar kernels form).
+template <bool C, class A, class B> struct TypeSel { typedef A type; };
+template <class A, class B> struct TypeSel<false, A, B> { typedef B type; };
+
+// The learned block as one lane of a patient's DPP quad sees it: MR = (D-4)/4 rows of tanh(W y + b).  The weights are kept
+// pre-multiplied by 2 log2(e), so tanh(z) = 1 - 2 / (exp2(z') + 1) needs no scaling instruction.
+//   MR == 2: the two rows are the two halves of packed registers: wp[i] = (W[row0][i], W[row1][i]); a stage is D
+//            v_pk_fma_f32 with the state component broadcast through op_sel, the result is the Own pair directly, and the
+//            weight gradient dw[i] += u * Y_i has the same shape.  Every broadcast operand is a scalar of its own (an
+//            element of a pair costs a v_mov when it is the odd one), so the stage state is kept as D floats;
+//   MR == 1: wp[ip] = (W[row][2ip], W[row][2ip+1]); .x sums the even columns from the bias, .y the odd ones, one add
+//            joins them; the stage state is kept as D/2 pairs.
 template <int D>
 struct MlRows {
   static constexpr int M = D - 4, MR = M / 4, DP = D / 2, MP = M / 2;
+  static constexpr int NW = MR == 2 ? D : DP;   // packed weight registers per lane
+  static constexpr int NU = MR == 2 ? M : MP;   // registers of an all-gathered cotangent
+  static constexpr float kTanhScale = 2.885390081777927f;  // 2 log2(e)
   typedef typename OwnSel<MR>::type Own;
-  f2 wp[MR][DP];
-  float bias[MR];
+  typedef typename TypeSel<MR == 2, float, f2>::type Elem;
+  struct Stage { Elem v[NW]; };  // the full stage state Y as this lane holds it
+  struct Gath { Elem v[NU]; };   // all-gathered learned-block vector (u of the VJP)
+  f2 wp[NW];
+  Own bias;
   HODE_DEV void load(const float* __restrict__ W, const float* __restrict__ b, int q) {
+    if constexpr (MR == 2) {
 #pragma unroll
-    for (int r = 0; r < MR; ++r) {
-      const int rowi = q * MR + r;
+      for (int i = 0; i < D; ++i) wp[i] = kTanhScale * pair2(W[(2 * q) * D + i], W[(2 * q + 1) * D + i]);
+      bias = kTanhScale * pair2(b[2 * q], b[2 * q + 1]);
+    } else {
 #pragma unroll
-      for (int ip = 0; ip < DP; ++ip) wp[r][ip] = pair2(W[rowi * D + 2 * ip], W[rowi * D + 2 * ip + 1]);
-      bias[r] = b[rowi];
+      for (int ip = 0; ip < DP; ++ip) wp[ip] = kTanhScale * pair2(W[q * D + 2 * ip], W[q * D + 2 * ip + 1]);
+      bias = kTanhScale * b[q];
     }
   }
-  // all-gather of the quad's own components into the pairs Y2[2..DP) (component 4 + j lives in lane j / MR)
-  static HODE_DEV void gather(Own v, f2* __restrict__ out) {
+  // all-gather of a quad's own components (component j lives in lane j / MR)
+  static HODE_DEV void gather(Own v, Elem* __restrict__ out) {
     if constexpr (MR == 2) {
-      out[0] = pair2(quad_bcast<0>(v.x), quad_bcast<0>(v.y));
-      out[1] = pair2(quad_bcast<1>(v.x), quad_bcast<1>(v.y));
-      out[2] = pair2(quad_bcast<2>(v.x), quad_bcast<2>(v.y));
-      out[3] = pair2(quad_bcast<3>(v.x), quad_bcast<3>(v.y));
+      out[0] = quad_bcast<0>(v.x); out[1] = quad_bcast<0>(v.y);
+      out[2] = quad_bcast<1>(v.x); out[3] = quad_bcast<1>(v.y);
+      out[4] = quad_bcast<2>(v.x); out[5] = quad_bcast<2>(v.y);
+      out[6] = quad_bcast<3>(v.x); out[7] = quad_bcast<3>(v.y);
     } else {
       out[0] = pair2(quad_bcast<0>(v), quad_bcast<1>(v));
       out[1] = pair2(quad_bcast<2>(v), quad_bcast<3>(v));
     }
   }
-  HODE_DEV Own rhs(const f2 (&Y2)[DP]) const {
-    float z[MR];
-#pragma unroll
-    for (int r = 0; r < MR; ++r) {
-      f2 acc = pair2(bias[r], 0.f);
-#pragma unroll
-      for (int ip = 0; ip < DP; ++ip) acc = vfma(wp[r][ip], Y2[ip], acc);
-      z[r] = hsum(acc);
+  // stage state from the expert wave's 4 components and this quad's own ones
+  static HODE_DEV Stage stage(const float4& e, Own Yo) {
+    Stage Y;
+    if constexpr (MR == 2) {
+      Y.v[0] = e.x; Y.v[1] = e.y; Y.v[2] = e.z; Y.v[3] = e.w;
+      gather(Yo, Y.v + 4);
+    } else {
+      Y.v[0] = pair2(e.x, e.y);
+      Y.v[1] = pair2(e.z, e.w);
+      gather(Yo, Y.v + 2);
     }
-    if constexpr (MR == 2) return tanh_f32(pair2(z[0], z[1]));
-    else return tanh_f32(z[0]);
+    return Y;
+  }
+  static HODE_DEV Own tanh_scaled(Own z) {  // z already carries the factor 2 log2(e)
+    if constexpr (MR == 2) {
+      const f2 e = pair2(__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)) + splat2(1.0f);
+      return vfma(pair2(__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)), splat2(-2.0f), splat2(1.0f));
+    } else {
+      return __builtin_fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z) + 1.0f), -2.0f, 1.0f);
+    }
+  }
+  HODE_DEV Own rhs(const Stage& Y) const {
+    if constexpr (MR == 2) {
+      // two interleaved accumulators: the result of a packed op cannot be consumed by the very next instruction (the
+      // assembler pads a dependent v_pk_fma chain with s_nop, 4.1 ns per link instead of 2.4)
+      f2 acc = bias, acc1 = splat2(0.f);
+#pragma unroll
+      for (int i = 0; i < D; i += 2) {
+        acc = vfma(wp[i], Y.v[i], acc);
+        acc1 = vfma(wp[i + 1], Y.v[i + 1], acc1);
+      }
+      return tanh_scaled(acc + acc1);
+    } else {
+      f2 acc = pair2(bias, 0.f);
+#pragma unroll
+      for (int ip = 0; ip < DP; ++ip) acc = vfma(wp[ip], Y.v[ip], acc);
+      return tanh_scaled(hsum(acc));
+    }
+  }
+  // dw += u (x) Y in the layout of wp
+  static HODE_DEV void outer_acc(f2 (&dw)[NW], Own u, const Stage& Y) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) dw[i] = vfma(u, Y.v[i], dw[i]);
+  }
+  static HODE_DEV float dw_at(const f2 (&dw)[NW], int r, int i) {
+    if constexpr (MR == 2) return r == 0 ? dw[i].x : dw[i].y;
+    else return (i & 1) ? dw[i / 2].y : dw[i / 2].x;
   }
   static HODE_DEV Own load_own(const float* __restrict__ src, int q) {
     if constexpr (MR == 2) {
@@ -134,13 +203,16 @@ struct MlRows {
   }
 };
 
-template <int D, int METHOD, bool ABLATE, bool HILL2, bool K1>
+template <int D, int METHOD, bool ABLATE, bool HILL2, bool K1, bool TAPE>
 HODE_DEV void split_fwd_body(const SplitArgs& a) {
   constexpr int NS = sp_stages<METHOD>();
   typedef MlRows<D> Ml;
   typedef typename Ml::Own Own;
   constexpr int DP = Ml::DP;
   __shared__ __attribute__((aligned(16))) float ring[2][4][kSplitPatients][4];
+  // Dose(t_s) of the 4 stages of a step, written by the learned waves (stage q by quad lane q) one step ahead of the
+  // expert wave: dring[n & 1] holds step n
+  __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][4];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int b0 = blockIdx.x * kSplitPatients;
@@ -152,11 +224,8 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     const int slot = lane;
     const bool live = slot < kSplitPatients && b0 + slot < a.B;
     const int p = min(b0 + (slot < kSplitPatients ? slot : 0), a.B - 1);
-    DoseSched<K1> ds;
-    ds.dosage = a.dosage[p];
-    ds.K = a.K;
-    ds.taus = a.dose_times + (size_t)p * a.K;
-    ds.tau0 = K1 ? ds.taus[0] : 0.f;
+    const int rslot = slot < kSplitPatients ? slot : 0;
+    const unsigned lane_h = (unsigned)p * D, lane_t = (unsigned)p * 4;  // 32-bit lane offsets on wave-uniform bases
     MlSlice<4, 1> none;
     float own1[1];
     // the state as two packed pairs (Disease, ImmuneReact), (Immunity, Dose2): the stage algebra is 2 instructions wide
@@ -167,27 +236,41 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       yb = pair2(v.z, v.w);
       if (live) *reinterpret_cast<float4*>(a.h + (size_t)p * D) = v;
     }
+    // the grid points are fetched two iterations before they are used: a load that is waited for on the spot costs a
+    // memory round trip per step
+    float t_cur = a.t[0], t_nx = a.t[min(1, a.T - 1)];
+    __syncthreads();  // the learned waves' prologue fills dring for steps 0 and 1
     for (int it = 0; it < a.T; ++it) {
+      const float t_nn = a.t[min(it + 2, a.T - 1)];
       if (it + 1 < a.T) {
-        const SpTimes st(a.t, it, a.perturb, METHOD);
+        const float dt = t_nx - t_cur;
+        const float4 dz = *reinterpret_cast<const float4*>(&dring[it & 1][rslot][0]);
+        const float dose[4] = {dz.x, dz.y, dz.z, dz.w};
+        float* __restrict__ tape_it = TAPE ? a.tape + (size_t)it * (NS - 1) * a.B * 4 : nullptr;
         f2 ka[4], kb[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) ka[s] = kb[s] = splat2(0.f);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const f2 Ya = sp_stage_state<METHOD>(s, ya, st.dt, ka[0], ka[1], ka[2]);
-          const f2 Yb = sp_stage_state<METHOD>(s, yb, st.dt, kb[0], kb[1], kb[2]);
+          const f2 Ya = sp_stage_state<METHOD>(s, ya, dt, ka[0], ka[1], ka[2]);
+          const f2 Yb = sp_stage_state<METHOD>(s, yb, dt, kb[0], kb[1], kb[2]);
           if (slot < kSplitPatients) *reinterpret_cast<float4*>(&ring[it & 1][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
+          if constexpr (TAPE) {
+            if (s >= 1 && live)
+              *reinterpret_cast<float4*>(tape_it + ((unsigned)(s - 1) * (unsigned)a.B * 4u + lane_t)) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
+          }
           const float Y[4] = {Ya.x, Ya.y, Yb.x, Yb.y};
           float k[4];
-          roche_rhs<4, 1, ABLATE, HILL2>(th, none, ds.at(st.ts[s], th.kel).v, Y, k, own1);
+          roche_rhs<4, 1, ABLATE, HILL2>(th, none, dose[s], Y, k, own1);
           ka[s] = pair2(k[0], k[1]);
           kb[s] = pair2(k[2], k[3]);
         }
-        ya = sp_advance<METHOD>(ya, st.dt, ka[0], ka[1], ka[2], ka[3]);
-        yb = sp_advance<METHOD>(yb, st.dt, kb[0], kb[1], kb[2], kb[3]);
-        if (live) *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + (size_t)p * D) = make_float4(ya.x, ya.y, yb.x, yb.y);
+        ya = sp_advance<METHOD>(ya, dt, ka[0], ka[1], ka[2], ka[3]);
+        yb = sp_advance<METHOD>(yb, dt, kb[0], kb[1], kb[2], kb[3]);
+        if (live) *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + lane_h) = make_float4(ya.x, ya.y, yb.x, yb.y);
       }
+      t_cur = t_nx;
+      t_nx = t_nn;
       __syncthreads();
     }
     if (a.status) {
@@ -202,12 +285,28 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     const int p = min(b0 + slot, a.B - 1);
     Ml ml;
     ml.load(a.w1, a.b1, q);
+    DoseSched<K1> ds;
+    ds.dosage = a.dosage[p];
+    ds.K = a.K;
+    ds.taus = a.dose_times + (size_t)p * a.K;
+    ds.tau0 = K1 ? ds.taus[0] : 0.f;
+    // Dose(t) at stage q of step n for the expert wave (it reads all four stages with one ds_read_b128)
+    auto dose_step = [&](int n, float t0, float t1) {  // lanes q >= NS write a value nobody reads
+      dring[n & 1][slot][q] = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel).v;
+    };
+    float t_a = a.t[0], t_b = a.t[min(1, a.T - 1)], t_c = a.t[min(2, a.T - 1)], t_d = a.t[min(3, a.T - 1)];
+    if (a.T >= 2) dose_step(0, t_a, t_b);
+    if (a.T >= 3) dose_step(1, t_b, t_c);
     Own yo = Ml::load_own(a.y0 + (size_t)p * D, q);
     if (live) Ml::store_own(a.h + (size_t)p * D, q, yo);
+    __syncthreads();  // doses of steps 0 and 1 are in place
     __syncthreads();  // iteration 0: the expert wave fills ring[0]
     for (int it = 1; it < a.T; ++it) {
       const int n = it - 1;
-      const float dt = a.t[n + 1] - a.t[n];
+      const float t_e = a.t[min(it + 3, a.T - 1)];  // t_a..t_d = t[it-1..it+2]
+      const float dt = t_b - t_a;
+      // the expert wave is at step `it` now and reads dring[it & 1]; past the last step this writes an unread slot
+      dose_step(it + 1, t_c, t_d);
       Own k[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) k[s] = vsplat<Own>(0.f);
@@ -215,14 +314,11 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       for (int s = 0; s < NS; ++s) {
         const Own Yo = sp_stage_state<METHOD>(s, yo, dt, k[0], k[1], k[2]);
         const float4 e = *reinterpret_cast<const float4*>(&ring[n & 1][s][slot][0]);
-        f2 Y2[DP];
-        Y2[0] = pair2(e.x, e.y);
-        Y2[1] = pair2(e.z, e.w);
-        Ml::gather(Yo, Y2 + 2);
-        k[s] = ml.rhs(Y2);
+        k[s] = ml.rhs(Ml::stage(e, Yo));
       }
       yo = sp_advance<METHOD>(yo, dt, k[0], k[1], k[2], k[3]);
       if (live) Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
+      t_a = t_b; t_b = t_c; t_c = t_d; t_d = t_e;
       __syncthreads();
     }
     if (a.status) {
@@ -252,6 +348,7 @@ struct SplitBwdArgs {
   float* __restrict__ grad_y0;
   float* __restrict__ part_ml;   // [3 * nblk][M*D + M]
   float* __restrict__ part_th;   // [nblk][kNTheta]
+  const float* __restrict__ tape;  // TAPE: what the forward kernel left (see SplitArgs)
   int B, T, K, perturb;
 };
 
@@ -294,15 +391,19 @@ struct F4 {  // the expert wave's 4 components as two packed pairs
 HODE_DEV F4 operator*(float s, const F4& v) { return F4{s * v.a, s * v.b}; }
 HODE_DEV F4 vfma(float s, const F4& x, const F4& y) { return F4{vfma(s, x.a, y.a), vfma(s, x.b, y.b)}; }
 
-template <int D, int METHOD, bool ABLATE, bool HILL2, bool NEED_TH, bool K1>
+template <int D, int METHOD, bool ABLATE, bool HILL2, bool NEED_TH, bool K1, bool TAPE>
 HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   constexpr int NS = sp_stages<METHOD>();
   typedef MlRows<D> Ml;
   typedef typename Ml::Own Own;
   constexpr int M = Ml::M, MR = Ml::MR, DP = Ml::DP, MP = Ml::MP;
   __shared__ __attribute__((aligned(16))) float yring[2][4][kSplitPatients][4];   // expert stage states
-  __shared__ __attribute__((aligned(16))) float cring[2][4][kSplitPatients][4];   // learned block -> expert cotangent
-  __shared__ __attribute__((aligned(16))) float dring[2][4][kSplitPatients][2];   // Dose(t_s), dDose/dkel
+  // learned block -> expert cotangent; row kSplitPatients stays zero: the expert wave's 16 spare lanes read it, so that
+  // their (masked) cotangent stays exactly zero without a per-stage multiply
+  __shared__ __attribute__((aligned(16))) float cring[2][4][kSplitPatients + 1][4];
+  // Dose(t_s) [0..3] and dDose/dkel [4..7] of the 4 stages; written by the expert wave when it re-integrates, by the
+  // learned waves (stage q by quad lane q) when the stage states come from the tape
+  __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][8];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int b0 = blockIdx.x * kSplitPatients;
@@ -323,35 +424,60 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     ds.taus = a.dose_times + (size_t)p * a.K;
     ds.tau0 = K1 ? ds.taus[0] : 0.f;
     const float ln_ec50 = log_f32(th.ec50);
+    const int cslot = mine ? lane : kSplitPatients;
+    if (lane < 32) (&cring[lane >> 4][(lane >> 2) & 3][kSplitPatients][0])[lane & 3] = 0.f;
+    const unsigned lane_h = (unsigned)p * D, lane_t = (unsigned)p * 4;  // 32-bit lane offsets on wave-uniform bases
     MlSlice<4, 1> none;
     MlColSlice<4, 1> nonec;
     GradAcc<4, 1> acc;
     acc.zero();
     float own1[1] = {0.f};
 
-    // (a): stage states + doses of step m into ring buffer `par`
-    auto recompute = [&](int m, int par) {
-      const SpTimes st(a.t, m, a.perturb, METHOD);
-      const float4 hv = *reinterpret_cast<const float4*>(a.h + (size_t)m * row + (size_t)p * D);
-      const f2 ya = pair2(hv.x, hv.y), yb = pair2(hv.z, hv.w);
-      f2 ka[4], kb[4];
+    // (a): stage states + doses of step m into ring buffer `par`.  Without a tape the stages are re-integrated; with
+    // one, fetch() issues the loads an iteration's worth of work ahead of publish().
+    float tp[4][4];  // plain floats: an array of float4 is not promoted to registers
+    auto fetch = [&](int m) {
+      const float4 v = *reinterpret_cast<const float4*>(a.h + (size_t)m * row + lane_h);
+      tp[0][0] = v.x; tp[0][1] = v.y; tp[0][2] = v.z; tp[0][3] = v.w;
+      if constexpr (TAPE) {
+        const float* __restrict__ tape_m = a.tape + (size_t)m * (NS - 1) * a.B * 4;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ka[s] = kb[s] = splat2(0.f);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const f2 Ya = sp_stage_state<METHOD>(s, ya, st.dt, ka[0], ka[1], ka[2]);
-        const f2 Yb = sp_stage_state<METHOD>(s, yb, st.dt, kb[0], kb[1], kb[2]);
-        const DoseVal dv = ds.at(st.ts[s], th.kel);
-        if (mine) {
-          *reinterpret_cast<float4*>(&yring[par][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
-          *reinterpret_cast<float2*>(&dring[par][s][slot][0]) = make_float2(dv.v, dv.dk);
+        for (int s = 1; s < NS; ++s) {
+          const float4 u = *reinterpret_cast<const float4*>(tape_m + ((unsigned)(s - 1) * (unsigned)a.B * 4u + lane_t));
+          tp[s][0] = u.x; tp[s][1] = u.y; tp[s][2] = u.z; tp[s][3] = u.w;
         }
-        if (s + 1 < NS) {
-          const float Y[4] = {Ya.x, Ya.y, Yb.x, Yb.y};
-          float k[4];
-          roche_rhs<4, 1, ABLATE, HILL2>(th, none, dv.v, Y, k, own1);
-          ka[s] = pair2(k[0], k[1]);
-          kb[s] = pair2(k[2], k[3]);
+      }
+    };
+    auto publish = [&](int m, int par) {
+      if constexpr (TAPE) {
+        if (mine) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            *reinterpret_cast<float4*>(&yring[par][s][slot][0]) = make_float4(tp[s][0], tp[s][1], tp[s][2], tp[s][3]);
+        }
+      } else {
+        const SpTimes st(a.t, m, a.perturb, METHOD);
+        const f2 ya = pair2(tp[0][0], tp[0][1]), yb = pair2(tp[0][2], tp[0][3]);
+        f2 ka[4], kb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ka[s] = kb[s] = splat2(0.f);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const f2 Ya = sp_stage_state<METHOD>(s, ya, st.dt, ka[0], ka[1], ka[2]);
+          const f2 Yb = sp_stage_state<METHOD>(s, yb, st.dt, kb[0], kb[1], kb[2]);
+          const DoseVal dv = ds.at(st.ts[s], th.kel);
+          if (mine) {
+            *reinterpret_cast<float4*>(&yring[par][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
+            dring[par][slot][s] = dv.v;
+            dring[par][slot][4 + s] = dv.dk;
+          }
+          if (s + 1 < NS) {
+            const float Y[4] = {Ya.x, Ya.y, Yb.x, Yb.y};
+            float k[4];
+            roche_rhs<4, 1, ABLATE, HILL2>(th, none, dv.v, Y, k, own1);
+            ka[s] = pair2(k[0], k[1]);
+            kb[s] = pair2(k[2], k[3]);
+          }
         }
       }
     };
@@ -362,26 +488,39 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       lam.a = lv * pair2(g4.x, g4.y);
       lam.b = lv * pair2(g4.z, g4.w);
     }
-    if (T >= 2) recompute(T - 2, 0);
+    if (T >= 2) {
+      fetch(T - 2);
+      publish(T - 2, 0);
+    }
+    float t_hi = a.t[T - 1], t_lo = a.t[max(T - 2, 0)];  // grid points of step m, fetched an iteration ahead
     __syncthreads();
     for (int k = 0; k < T; ++k) {
+      if (T - 3 - k >= 0) fetch(T - 3 - k);
+      const float t_nx = a.t[max(T - 2 - k, 0)];
       if (k >= 1) {
         // ---- (b) adjoint of step m = T-1-k
         const int m = T - 1 - k;
         const int par = (k - 1) & 1;
-        const float dt = a.t[m + 1] - a.t[m];
+        const float dt = t_hi - t_lo;
+        t_hi = t_lo;
+        t_lo = t_nx;
         float Y[4][4];
         F4 cs[4];
         DoseVal dv[4];
+        {
+          const float4 d0 = *reinterpret_cast<const float4*>(&dring[par][slot][0]);
+          const float4 d1 = *reinterpret_cast<const float4*>(&dring[par][slot][4]);
+          dv[0].v = d0.x; dv[1].v = d0.y; dv[2].v = d0.z; dv[3].v = d0.w;
+          dv[0].dk = d1.x; dv[1].dk = d1.y; dv[2].dk = d1.z; dv[3].dk = d1.w;
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           const float4 yv = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
-          const float4 cv = *reinterpret_cast<const float4*>(&cring[par][s][slot][0]);
-          const float2 d2 = *reinterpret_cast<const float2*>(&dring[par][s][slot][0]);
+          const float4 cv = *reinterpret_cast<const float4*>(&cring[par][s][cslot][0]);
           Y[s][0] = yv.x; Y[s][1] = yv.y; Y[s][2] = yv.z; Y[s][3] = yv.w;
-          cs[s].a = lv * pair2(cv.x, cv.y);
-          cs[s].b = lv * pair2(cv.z, cv.w);
-          dv[s].v = d2.x; dv[s].dk = d2.y;
+          // no masking: a patient beyond the batch has a zero cotangent in the learned waves too (c_s is linear in it)
+          cs[s].a = pair2(cv.x, cv.y);
+          cs[s].b = pair2(cv.z, cv.w);
         }
         sp_adjoint_step<METHOD>(lam, dt, [&](int s, const F4& gs) {
           const float g[4] = {gs.a.x, gs.a.y, gs.b.x, gs.b.y};
@@ -392,12 +531,12 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
           r.b += pair2(av[2], av[3]);
           return r;
         });
-        const float4 g4 = *reinterpret_cast<const float4*>(a.grad_h + (size_t)m * row + (size_t)p * D);
+        const float4 g4 = *reinterpret_cast<const float4*>(a.grad_h + (size_t)m * row + lane_h);
         lam.a = vfma(lv, pair2(g4.x, g4.y), lam.a);
         lam.b = vfma(lv, pair2(g4.z, g4.w), lam.b);
       }
       // ---- (a) stage states of step T-3-k for the learned waves' next iteration
-      if (T - 3 - k >= 0) recompute(T - 3 - k, (k + 1) & 1);
+      if (T - 3 - k >= 0) publish(T - 3 - k, (k + 1) & 1);
       __syncthreads();
     }
     if (live) *reinterpret_cast<float4*>(a.grad_y0 + (size_t)p * D) = make_float4(lam.a.x, lam.a.y, lam.b.x, lam.b.y);
@@ -415,25 +554,33 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     const float lv = live ? 1.0f : 0.0f;
     Ml ml;
     ml.load(a.w1, a.b1, q);
-    // transposed operands of a = W^T u.  wc2: column q of W (the expert component this lane reports to the expert wave),
-    // paired over the rows j;  MR == 2: wtp[j] = (W[j][own0], W[j][own1]) (row-paired, the result is the Own pair);
-    // MR == 1: wt2[jp] = (W[2jp][own], W[2jp+1][own]).
-    f2 wc2[MP], wtp[MR == 2 ? M : MP];
-#pragma unroll
-    for (int jp = 0; jp < MP; ++jp) wc2[jp] = pair2(a.w1[(2 * jp) * D + q], a.w1[(2 * jp + 1) * D + q]);
+    // transposed operands of a = W^T u.  wc: column q of W (the expert component this lane reports to the expert wave).
+    // MR == 2: wc[j] scalars, wtp[j] = (W[j][own0], W[j][own1]) (row-paired, the result is the Own pair);
+    // MR == 1: wc[jp] = (W[2jp][q], W[2jp+1][q]), wtp[jp] = (W[2jp][own], W[2jp+1][own]) (paired over the rows j).
+    typename Ml::Elem wc[Ml::NU];
+    f2 wtp[Ml::NU];
     if constexpr (MR == 2) {
 #pragma unroll
-      for (int j = 0; j < M; ++j) wtp[j] = pair2(a.w1[j * D + 4 + 2 * q], a.w1[j * D + 4 + 2 * q + 1]);
+      for (int j = 0; j < M; ++j) {
+        wc[j] = a.w1[j * D + q];
+        wtp[j] = pair2(a.w1[j * D + 4 + 2 * q], a.w1[j * D + 4 + 2 * q + 1]);
+      }
     } else {
 #pragma unroll
-      for (int jp = 0; jp < MP; ++jp) wtp[jp] = pair2(a.w1[(2 * jp) * D + 4 + q], a.w1[(2 * jp + 1) * D + 4 + q]);
+      for (int jp = 0; jp < MP; ++jp) {
+        wc[jp] = pair2(a.w1[(2 * jp) * D + q], a.w1[(2 * jp + 1) * D + q]);
+        wtp[jp] = pair2(a.w1[(2 * jp) * D + 4 + q], a.w1[(2 * jp + 1) * D + 4 + q]);
+      }
     }
-    f2 dw2[MR][DP];
+    f2 dw[Ml::NW];
     Own db = vsplat<Own>(0.f);
 #pragma unroll
-    for (int r = 0; r < MR; ++r)
-#pragma unroll
-      for (int ip = 0; ip < DP; ++ip) dw2[r][ip] = splat2(0.f);
+    for (int i = 0; i < Ml::NW; ++i) dw[i] = splat2(0.f);
+    DoseSched<K1> ds;
+    ds.dosage = a.dosage[p];
+    ds.K = a.K;
+    ds.taus = a.dose_times + (size_t)p * a.K;
+    ds.tau0 = K1 ? ds.taus[0] : 0.f;
     Own lam = lv * Ml::load_own(a.grad_h + (size_t)(T - 1) * row + (size_t)p * D, q);
     // the operands of iteration k+1 are fetched during iteration k (the state is needed by the very first instruction of
     // an iteration: an un-hidden HBM round trip would cost a quarter of it)
@@ -443,20 +590,30 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       yo_nx = Ml::load_own(a.h + (size_t)m0 * row + (size_t)p * D, q);
       gh_nx = Ml::load_own(a.grad_h + (size_t)m0 * row + (size_t)p * D, q);
     }
+    float t_hi = a.t[T - 1], t_lo = a.t[max(T - 2, 0)];  // grid points of step m, fetched an iteration ahead
     __syncthreads();  // the expert wave's prologue fills ring 0
     for (int k = 0; k < T; ++k) {
+      const float t_nx = a.t[max(T - 3 - k, 0)];
       if (k <= T - 2) {
         const int m = T - 2 - k;
         const int par = k & 1;
-        const float dt = a.t[m + 1] - a.t[m];
+        const float t0 = t_lo, t1 = t_hi;
+        const float dt = t1 - t0;
+        t_hi = t_lo;
+        t_lo = t_nx;
         const Own yo = yo_nx, gh = gh_nx;
         {
           const int mn = m >= 1 ? m - 1 : 0;  // clamped: the last prefetch is simply unused
           yo_nx = Ml::load_own(a.h + (size_t)mn * row + (size_t)p * D, q);
           gh_nx = Ml::load_own(a.grad_h + (size_t)mn * row + (size_t)p * D, q);
         }
+        if constexpr (TAPE) {  // the expert wave adjoins this step next iteration: its doses, stage q by quad lane q
+          const DoseVal dq = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel);  // lanes q >= NS: unread
+          dring[par][slot][q] = dq.v;
+          if constexpr (NEED_TH) dring[par][slot][4 + q] = dq.dk;
+        }
         // ---- recompute the learned stage derivatives
-        f2 Y2[4][DP];
+        typename Ml::Stage Y[4];
         Own so[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) so[s] = vsplat<Own>(0.f);
@@ -464,43 +621,36 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         for (int s = 0; s < NS; ++s) {
           const Own Yo = sp_stage_state<METHOD>(s, yo, dt, so[0], so[1], so[2]);
           const float4 e = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
-          Y2[s][0] = pair2(e.x, e.y);
-          Y2[s][1] = pair2(e.z, e.w);
-          Ml::gather(Yo, Y2[s] + 2);
-          so[s] = ml.rhs(Y2[s]);
+          Y[s] = Ml::stage(e, Yo);
+          so[s] = ml.rhs(Y[s]);
         }
         // ---- adjoint of the stages
         sp_adjoint_step<METHOD>(lam, dt, [&](int s, Own gs) {
           const Own u = gs * vfma(-so[s], so[s], vsplat<Own>(1.0f));
           db += u;
-          f2 uf2[MP];
-          Ml::gather(u, uf2);
+          Ml::outer_acc(dw, u, Y[s]);
+          typename Ml::Gath uf;
+          Ml::gather(u, uf.v);
           if constexpr (MR == 2) {
+            float cq = 0.f;
+            f2 av = splat2(0.f), av1 = splat2(0.f);  // two chains, see MlRows::rhs
 #pragma unroll
-            for (int ip = 0; ip < DP; ++ip) {
-              dw2[0][ip] = vfma(u.x, Y2[s][ip], dw2[0][ip]);
-              dw2[1][ip] = vfma(u.y, Y2[s][ip], dw2[1][ip]);
+            for (int j = 0; j < M; j += 2) {
+              cq = __builtin_fmaf(wc[j], uf.v[j], cq);
+              av = vfma(wtp[j], uf.v[j], av);
+              cq = __builtin_fmaf(wc[j + 1], uf.v[j + 1], cq);
+              av1 = vfma(wtp[j + 1], uf.v[j + 1], av1);
             }
+            cring[par][s][slot][q] = cq;
+            return av + av1;
           } else {
-#pragma unroll
-            for (int ip = 0; ip < DP; ++ip) dw2[0][ip] = vfma(u, Y2[s][ip], dw2[0][ip]);
-          }
-          f2 c2 = splat2(0.f);
-#pragma unroll
-          for (int jp = 0; jp < MP; ++jp) c2 = vfma(wc2[jp], uf2[jp], c2);
-          cring[par][s][slot][q] = hsum(c2);
-          if constexpr (MR == 2) {
-            f2 av = splat2(0.f);
+            f2 c2 = splat2(0.f), a2 = splat2(0.f);
 #pragma unroll
             for (int jp = 0; jp < MP; ++jp) {
-              av = vfma(wtp[2 * jp], uf2[jp].x, av);
-              av = vfma(wtp[2 * jp + 1], uf2[jp].y, av);
+              c2 = vfma(wc[jp], uf.v[jp], c2);
+              a2 = vfma(wtp[jp], uf.v[jp], a2);
             }
-            return av;
-          } else {
-            f2 a2 = splat2(0.f);
-#pragma unroll
-            for (int jp = 0; jp < MP; ++jp) a2 = vfma(wtp[jp], uf2[jp], a2);
+            cring[par][s][slot][q] = hsum(c2);
             return hsum(a2);
           }
         });
@@ -514,7 +664,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     for (int r = 0; r < MR; ++r) {
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        const float v = wave_sum_stride4((i & 1) ? dw2[r][i / 2].y : dw2[r][i / 2].x);
+        const float v = wave_sum_stride4(Ml::dw_at(dw, r, i));
         if (lane < 4) out[(lane * MR + r) * D + i] = v;
       }
       float dbr;
@@ -560,20 +710,20 @@ __global__ __launch_bounds__(64) void split_fold_kernel(const float* __restrict_
   *dst = overwrite ? s : *dst + s;
 }
 
-template <int D, int METHOD, bool ABLATE, bool NEED_TH>
+template <int D, int METHOD, bool ABLATE, bool NEED_TH, bool TAPE>
 __global__ __launch_bounds__(256) void split_bwd_kernel(SplitBwdArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
-  if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true>(a);
-  else if (hill2) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, false>(a);
-  else split_bwd_body<D, METHOD, ABLATE, false, NEED_TH, false>(a);
+  if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true, TAPE>(a);
+  else if (hill2) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, false, TAPE>(a);
+  else split_bwd_body<D, METHOD, ABLATE, false, NEED_TH, false, TAPE>(a);
 }
 
-template <int D, int METHOD, bool ABLATE>
+template <int D, int METHOD, bool ABLATE, bool TAPE>
 __global__ __launch_bounds__(256) void split_fwd_kernel(SplitArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
-  if (hill2 && a.K == 1) split_fwd_body<D, METHOD, ABLATE, true, true>(a);
-  else if (hill2) split_fwd_body<D, METHOD, ABLATE, true, false>(a);
-  else split_fwd_body<D, METHOD, ABLATE, false, false>(a);
+  if (hill2 && a.K == 1) split_fwd_body<D, METHOD, ABLATE, true, true, TAPE>(a);
+  else if (hill2) split_fwd_body<D, METHOD, ABLATE, true, false, TAPE>(a);
+  else split_fwd_body<D, METHOD, ABLATE, false, false, TAPE>(a);
 }
 
 }  // namespace hode
@@ -583,10 +733,13 @@ namespace {
 template <int D, bool ABLATE>
 int split_method(const hode_solve_desc* d, const hode::SplitArgs& a, hipStream_t s) {
   const dim3 grid((d->batch + hode::kSplitPatients - 1) / hode::kSplitPatients), block(256);
+#define HODE_SPLIT_FWD(M)                                                                                 \
+  if (a.tape) hipLaunchKernelGGL((hode::split_fwd_kernel<D, M, ABLATE, true>), grid, block, 0, s, a);     \
+  else hipLaunchKernelGGL((hode::split_fwd_kernel<D, M, ABLATE, false>), grid, block, 0, s, a);
   switch (d->method) {
-    case HODE_METHOD_EULER: hipLaunchKernelGGL((hode::split_fwd_kernel<D, HODE_METHOD_EULER, ABLATE>), grid, block, 0, s, a); break;
-    case HODE_METHOD_MIDPOINT: hipLaunchKernelGGL((hode::split_fwd_kernel<D, HODE_METHOD_MIDPOINT, ABLATE>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((hode::split_fwd_kernel<D, HODE_METHOD_RK4_38, ABLATE>), grid, block, 0, s, a); break;
+    case HODE_METHOD_EULER: HODE_SPLIT_FWD(HODE_METHOD_EULER) break;
+    case HODE_METHOD_MIDPOINT: HODE_SPLIT_FWD(HODE_METHOD_MIDPOINT) break;
+    default: HODE_SPLIT_FWD(HODE_METHOD_RK4_38) break;
   }
   return hode::hip_fail(hipGetLastError(), "split kernel launch");
 }
@@ -599,8 +752,13 @@ template <int D, bool ABLATE>
 int split_bwd_method(const hode_solve_desc* d, const hode::SplitBwdArgs& a, hipStream_t s) {
   const dim3 grid((d->batch + hode::kSplitPatients - 1) / hode::kSplitPatients), block(256);
 #define HODE_SPLIT_BWD(M)                                                                                        \
-  if (d->need_theta_grad) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true>), grid, block, 0, s, a);  \
-  else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false>), grid, block, 0, s, a);
+  if (d->need_theta_grad) {                                                                                      \
+    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, true>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, false>), grid, block, 0, s, a);            \
+  } else {                                                                                                       \
+    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, true>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, false>), grid, block, 0, s, a);           \
+  }
   switch (d->method) {
     case HODE_METHOD_EULER: HODE_SPLIT_BWD(HODE_METHOD_EULER) break;
     case HODE_METHOD_MIDPOINT: HODE_SPLIT_BWD(HODE_METHOD_MIDPOINT) break;
@@ -617,10 +775,21 @@ bool split_supported(const hode_solve_desc* d) { return d->latent_dim == 8 || d-
 
 static size_t al256s(size_t x) { return (x + 255) / 256 * 256; }
 
-size_t split_workspace_bytes(const hode_solve_desc* d) {
+static int n_stages(int method) { return method == HODE_METHOD_EULER ? 1 : (method == HODE_METHOD_MIDPOINT ? 2 : 4); }
+
+// [ learned-block partials | theta partials | tape (HODE_FLAG_TAPE) ]; the same buffer serves hode_rk_fwd and hode_rk_bwd
+static size_t split_partials_bytes(const hode_solve_desc* d) {
   const size_t nblk = (d->batch + kSplitPatients - 1) / kSplitPatients;
   const size_t M = d->latent_dim - 4;
   return al256s(nblk * 3 * (M * d->latent_dim + M) * sizeof(float)) + al256s(nblk * kNTheta * sizeof(float));
+}
+static size_t split_tape_bytes(const hode_solve_desc* d) {
+  if (!(d->flags & HODE_FLAG_TAPE) || d->n_times < 2) return 0;
+  return (size_t)(d->n_times - 1) * (n_stages(d->method) - 1) * d->batch * 4 * sizeof(float);
+}
+size_t split_workspace_bytes(const hode_solve_desc* d) { return split_partials_bytes(d) + split_tape_bytes(d); }
+static float* split_tape(const hode_solve_desc* d) {
+  return split_tape_bytes(d) ? (float*)((char*)d->workspace + split_partials_bytes(d)) : nullptr;
 }
 
 int split_rk_bwd(const hode_solve_desc* d, hipStream_t s) {
@@ -634,6 +803,7 @@ int split_rk_bwd(const hode_solve_desc* d, hipStream_t s) {
   a.part_ml = (float*)ws;
   a.part_th = (float*)(ws + al256s((size_t)nblk * 3 * Pml * sizeof(float)));
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
+  a.tape = split_tape(d);
   const bool abl = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
   int e;
   if (d->latent_dim == 8) e = abl ? split_bwd_method<8, true>(d, a, s) : split_bwd_method<8, false>(d, a, s);
@@ -651,6 +821,7 @@ int split_rk_fwd(const hode_solve_desc* d, hipStream_t s) {
   a.t = d->t; a.y0 = d->y0; a.dosage = d->dosage; a.dose_times = d->dose_times; a.theta = d->theta; a.w1 = d->w1; a.b1 = d->b1;
   a.h = d->h; a.status = d->status;
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
+  a.tape = split_tape(d);
   const bool abl = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
   if (d->latent_dim == 8) return abl ? split_method<8, true>(d, a, s) : split_method<8, false>(d, a, s);
   return abl ? split_method<12, true>(d, a, s) : split_method<12, false>(d, a, s);

@@ -16,7 +16,7 @@ METHODS = {"euler": METHOD_EULER, "midpoint": METHOD_MIDPOINT, "rk4": METHOD_RK4
 N_THETA = 16
 STATUS_NONFINITE, STATUS_DT_UNDERFLOW, STATUS_MAX_STEPS = 1, 2, 4
 WS_RK_FWD, WS_RK_BWD, WS_DOPRI5_FWD, WS_DOPRI5_BWD = 0, 1, 2, 3
-FLAG_SKIP_FOLD, FLAG_OVERWRITE_GRADS = 1, 2
+FLAG_SKIP_FOLD, FLAG_OVERWRITE_GRADS, FLAG_TAPE = 1, 2, 4
 
 
 class HodeError(RuntimeError):

@@ -14,7 +14,7 @@ from . import _lib as L
 
 class RocheRKPlan:
     def __init__(self, y0, theta, w, b, t, dosage, dose_times, method="rk4", ablate=False, perturb=False,
-                 lanes_per_patient=0, need_theta_grad=True):
+                 lanes_per_patient=0, need_theta_grad=True, tape=True):
         for x in (y0, theta, t, dosage, dose_times):
             if not x.is_cuda:
                 raise L.HodeError("hode: RocheRKPlan needs HIP-device tensors (no CPU fallback)")
@@ -56,10 +56,12 @@ class RocheRKPlan:
         d.grad_w1 = 0 if self.grad_w is None else self.grad_w.data_ptr()
         d.grad_b1 = 0 if self.grad_b is None else self.grad_b.data_ptr()
         d.grad_theta = self.grad_theta.data_ptr()
-        nbytes = self.lib.hode_workspace_bytes(d, L.WS_RK_BWD)
+        # one buffer for both launches: the backward's partial sums and (tape=True) the forward's stage tape
+        self.base_flags = L.FLAG_OVERWRITE_GRADS | (L.FLAG_TAPE if tape else 0)
+        d.flags = self.base_flags
+        nbytes = max(self.lib.hode_workspace_bytes(d, L.WS_RK_BWD), self.lib.hode_workspace_bytes(d, L.WS_RK_FWD))
         self.ws = torch.empty(max(nbytes, 4), device=self.dev, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
-        d.flags = L.FLAG_OVERWRITE_GRADS
         self.desc = d
         self._graph = None
 
@@ -84,11 +86,11 @@ class RocheRKPlan:
 
     def backward_kernel_only(self):
         """The adjoint kernel alone (HODE_FLAG_SKIP_FOLD, no accumulator memset): what a profiler reports as one kernel."""
-        self.desc.flags = L.FLAG_SKIP_FOLD
+        self.desc.flags = self.base_flags | L.FLAG_SKIP_FOLD
         try:
             L.check(self.lib.hode_rk_bwd(self.desc, torch.cuda.current_stream().cuda_stream), "hode_rk_bwd")
         finally:
-            self.desc.flags = L.FLAG_OVERWRITE_GRADS
+            self.desc.flags = self.base_flags
 
     def step(self):
         self.forward()

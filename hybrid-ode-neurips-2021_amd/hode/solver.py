@@ -64,6 +64,17 @@ class _RocheFixedGrid(torch.autograd.Function):
         d.lanes_per_patient = lanes
         d.t, d.y0, d.dosage, d.dose_times, d.theta = tc.data_ptr(), y0c.data_ptr(), dosc.data_ptr(), _ptr(dtc), thc.data_ptr()
         d.w1, d.b1, d.h, d.status = _ptr(wc), _ptr(bc), h.data_ptr(), _ptr(status)
+        # a backward will follow: let the forward leave its stage tape in the buffer the backward gets (HODE_FLAG_TAPE)
+        ws = None
+        if any(ctx.needs_input_grad[:4]):
+            d.flags = L.FLAG_TAPE
+            nbytes = lib.hode_workspace_bytes(d, L.WS_RK_FWD)
+            if nbytes:
+                ws = torch.empty(nbytes, device=y0.device, dtype=torch.uint8)
+                d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+            else:
+                d.flags = 0
+        ctx.tape_ws = ws
         with torch.cuda.device(y0.device):
             L.check(lib.hode_rk_fwd(d, _stream()), "hode_rk_fwd")
         if check_finite and int(status.item()) & L.STATUS_NONFINITE:
@@ -82,8 +93,8 @@ class _RocheFixedGrid(torch.autograd.Function):
         need_th = bool(ctx.needs_input_grad[1])
         gy0 = torch.empty((B, D), device=h.device, dtype=torch.float32)
         gth = torch.zeros(L.N_THETA, device=h.device, dtype=torch.float32)
-        gw = torch.zeros_like(wc) if has_w else None
-        gb = torch.zeros_like(bc) if has_w else None
+        gw = torch.empty_like(wc) if has_w else None  # HODE_FLAG_OVERWRITE_GRADS: the kernels store, no memset needed
+        gb = torch.empty_like(bc) if has_w else None
         d = L.new_solve_desc()
         d.rhs_kind = L.RHS_ROCHE_ABLATE if ablate else L.RHS_ROCHE
         d.method, d.perturb, d.batch, d.latent_dim, d.n_times = method, perturb, B, D, T
@@ -94,9 +105,12 @@ class _RocheFixedGrid(torch.autograd.Function):
         d.w1, d.b1, d.h = (_ptr(wc), _ptr(bc), h.data_ptr()) if has_w else (0, 0, h.data_ptr())
         d.grad_h, d.grad_y0 = gh.data_ptr(), gy0.data_ptr()
         d.grad_w1, d.grad_b1, d.grad_theta = _ptr(gw), _ptr(gb), gth.data_ptr()
+        d.flags = L.FLAG_OVERWRITE_GRADS | (L.FLAG_TAPE if ctx.tape_ws is not None else 0)
         nbytes = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
-        ws = torch.empty(max(nbytes, 4), device=h.device, dtype=torch.uint8)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        ws = ctx.tape_ws if ctx.tape_ws is not None else torch.empty(max(nbytes, 4), device=h.device, dtype=torch.uint8)
+        if ws.numel() < nbytes:
+            raise L.HodeError("hode: tape buffer of the forward (%d B) is smaller than the backward needs (%d B)" % (ws.numel(), nbytes))
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         with torch.cuda.device(h.device):
             L.check(lib.hode_rk_bwd(d, _stream()), "hode_rk_bwd")
         return gy0, (gth if need_th else None), gw, gb, None, None, None, None, None, None, None, None

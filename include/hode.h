@@ -61,6 +61,12 @@ extern "C" {
 #define HODE_FLAG_OVERWRITE_GRADS 2 /* backward: STORE grad_w1 / grad_b1 / grad_theta instead of accumulating into them (the
                                       caller then need not zero them).  hode_rk_bwd with the ROCHE kinds only; HODE_E_UNSUPPORTED elsewhere */
 
+#define HODE_FLAG_TAPE 4 /* fixed-grid ROCHE solves: hode_rk_fwd leaves the expert block's intermediate stage states in
+                            `workspace` and hode_rk_bwd reads them back instead of re-integrating every step.  Set it in
+                            BOTH calls, size the buffer with hode_workspace_bytes(d, HODE_WS_RK_FWD / _BWD) with the flag
+                            set, and hand the same, untouched buffer to both.  Costs 16 (stages-1) B per patient and grid
+                            interval of extra HBM traffic in each direction; layouts without a tape ignore the flag. */
+
 /* argument errors */
 #define HODE_E_NULL -1      /* a required pointer is NULL */
 #define HODE_E_SIZE -2      /* struct_size mismatch / non-positive dimension */

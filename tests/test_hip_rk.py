@@ -305,3 +305,31 @@ def test_plan_overwrite_flag_matches_accumulating_backward(lanes):
     assert torch.equal(gy0.cpu(), ref["gy0"])
     assert torch.equal(plan.grad_w.cpu(), ref["gw"]) and torch.equal(plan.grad_b.cpu(), ref["gb"])
     assert torch.equal(plan.grad_theta[:13].cpu(), ref["gtheta"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [8, 12])
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_split_tape_matches_recompute(D, method):
+    """HODE_FLAG_TAPE: the forward leaves the expert stage states in the workspace, the backward reads them instead of
+    re-integrating -- the same numbers, so every output must be bit-identical to the tape-less backward."""
+    dev = _dev()
+    from hode.plan import RocheRKPlan
+    from hode.solver import pack_theta
+    from oracle.rhs import THETA_NAMES
+    N, T = 101, 9
+    inp, f = _case(N, T, D, seed=7 + D)
+    cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(6)).to(dev)
+    theta = pack_theta([getattr(f, n).detach().to(dev) for n in THETA_NAMES], dev)
+    dosage, times = dose_schedule(inp["actions"], f.step_size)
+    outs = []
+    for tape in (False, True):
+        plan = RocheRKPlan(inp["z0"].to(dev), theta, f.ml_net[0].weight.detach().to(dev), f.ml_net[0].bias.detach().to(dev),
+                           inp["t"].to(dev), dosage.to(dev), times.to(dev), method=method, lanes_per_patient=48, tape=tape)
+        plan.grad_h.copy_(cot)
+        plan.forward()
+        gy0, flat = plan.backward()
+        torch.cuda.synchronize()
+        outs.append((plan.h.clone(), gy0.clone(), flat.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

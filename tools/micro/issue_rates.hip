@@ -12,8 +12,8 @@
   __global__ __launch_bounds__(64) void name(float* out, int iters, float a) {                                    \
     float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
     typedef float f2 __attribute__((ext_vector_type(2)));                                                        \
-    f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, pa = {a, a};                                   \
-    __shared__ float sm[256];                                                                                    \
+    typedef float f4 __attribute__((ext_vector_type(4))); f4 q0, q1; f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, pa = {a, a};                                   \
+    __shared__ float sm[1024];                                                                                    \
     sm[threadIdx.x] = x0;                                                                                        \
     unsigned addr = threadIdx.x * 4;                                                                             \
     for (int i = 0; i < iters; ++i) {                                                                            \
@@ -39,13 +39,22 @@ KERNEL(fma_dpp_src, asm volatile("v_fmac_f32_dpp %0, %4, %5 quad_perm:[1,1,1,1] 
 KERNEL(dpp_then_fma, asm volatile("v_mov_b32_dpp %1, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n v_fma_f32 %0, %1, %2, %0\n v_mov_b32_dpp %1, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n v_fma_f32 %0, %1, %2, %0" : "+v"(x0), "+v"(x1) : "v"(a));, 4)
 KERNEL(lds_rt, asm volatile("ds_write_b32 %1, %0\n s_waitcnt lgkmcnt(0)\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "+v"(x0) : "v"(addr) : "memory");, 1)
 KERNEL(lds_read_dep, asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_fma_f32 %0, %0, %2, %0" : "+v"(x0) : "v"(addr), "v"(a) : "memory");, 1)
+KERNEL(pk_dep_nop, asm volatile("v_pk_fma_f32 %0, %0, %1, %0\n s_nop 0\n v_pk_fma_f32 %0, %0, %1, %0\n s_nop 0\n v_pk_fma_f32 %0, %0, %1, %0\n s_nop 0\n v_pk_fma_f32 %0, %0, %1, %0\n s_nop 0" : "+v"(p0) : "v"(pa));, 4)
+KERNEL(fma_nop1, asm volatile("v_fma_f32 %0, %0, %1, %0\n s_nop 1\n v_fma_f32 %0, %0, %1, %0\n s_nop 1\n v_fma_f32 %0, %0, %1, %0\n s_nop 1\n v_fma_f32 %0, %0, %1, %0\n s_nop 1" : "+v"(x0) : "v"(a));, 4)
+KERNEL(fma_salu, asm volatile("v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1\n v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1\n v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1\n v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1" : "+v"(x0) : "v"(a) : "s20");, 4)
+KERNEL(fma_2salu, asm volatile("v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n v_fma_f32 %0, %0, %1, %0\n s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1" : "+v"(x0) : "v"(a) : "s20", "s21");, 4)
+KERNEL(fma_waitcnt, asm volatile("v_fma_f32 %0, %0, %1, %0\n s_waitcnt lgkmcnt(0)\n v_fma_f32 %0, %0, %1, %0\n s_waitcnt vmcnt(0)\n v_fma_f32 %0, %0, %1, %0\n s_waitcnt lgkmcnt(0)\n v_fma_f32 %0, %0, %1, %0\n s_waitcnt vmcnt(0)" : "+v"(x0) : "v"(a));, 4)
+KERNEL(exp_nop_fma, asm volatile("v_exp_f32 %0, %0\n s_nop 0\n v_fma_f32 %0, %0, %1, %0\n v_exp_f32 %0, %0\n s_nop 0\n v_fma_f32 %0, %0, %1, %0" : "+v"(x0) : "v"(a));, 2)
+KERNEL(exp2_pk, asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n s_nop 0\n v_pk_add_f32 %2, %2, %3" : "+v"(x0), "+v"(x1), "+v"(p0) : "v"(pa));, 1)
+KERNEL(dswrite_only, asm volatile("ds_write_b32 %1, %0\n ds_write_b32 %1, %0\n ds_write_b32 %1, %0\n ds_write_b32 %1, %0" : : "v"(x0), "v"(addr) : "memory");, 4)
+KERNEL(dsread_nowait, asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n v_fma_f32 %3, %3, %4, %3\n v_fma_f32 %3, %3, %4, %3" : "=v"(q0), "=v"(q1) : "v"(addr), "v"(x0), "v"(a) : "memory");, 4)
 KERNEL(barrier1, asm volatile("s_barrier" ::: "memory");, 1)
 
 #define RUN(name) run(#name, (void*)name, name##_per)
 static float* d;
 static void run(const char* nm, void* fn, int per_iter) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int iters = 4000;
+  const int iters = 1000;
   float a = 0.999f;
   void* args[] = {&d, (void*)&iters, &a};
   float ms = 0;
@@ -59,8 +68,9 @@ static void run(const char* nm, void* fn, int per_iter) {
   printf("%-14s %8.3f ms  %.3f ns/unit  %.2f cycles@2.4GHz\n", nm, ms, ms * 1e6 / n, ms * 1e6 / n * 2.4);
 }
 int main() {
+  setvbuf(stdout, NULL, _IONBF, 0);
   hipMalloc(&d, 1 << 24);
   RUN(fma_dep); RUN(fma_ind); RUN(pk_dep); RUN(pk_ind); RUN(pk_mul_ind); RUN(exp_dep); RUN(exp_ind); RUN(exp_fma_mix);
-  RUN(rcp_ind); RUN(dpp_dep); RUN(dpp_ind); RUN(fma_dpp_src); RUN(dpp_then_fma); RUN(lds_rt); RUN(lds_read_dep); RUN(barrier1);
+  RUN(rcp_ind); RUN(dpp_dep); RUN(dpp_ind); RUN(fma_dpp_src); RUN(dpp_then_fma); RUN(lds_rt); RUN(lds_read_dep); RUN(pk_dep_nop); RUN(fma_nop1); RUN(fma_waitcnt); RUN(exp_nop_fma); RUN(exp2_pk); RUN(dswrite_only); RUN(dsread_nowait); RUN(barrier1);
   return 0;
 }
