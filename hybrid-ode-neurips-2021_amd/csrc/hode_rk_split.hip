@@ -308,13 +308,16 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       // the expert wave is at step `it` now and reads dring[it & 1]; past the last step this writes an unread slot
       dose_step(it + 1, t_c, t_d);
       Own k[4];
+      float4 e[4];  // all four expert stage states up front: one LDS round trip per step instead of one per stage
+#pragma unroll
+      for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&ring[n & 1][s][slot][0]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
 #pragma unroll
       for (int s = 0; s < 4; ++s) k[s] = vsplat<Own>(0.f);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const Own Yo = sp_stage_state<METHOD>(s, yo, dt, k[0], k[1], k[2]);
-        const float4 e = *reinterpret_cast<const float4*>(&ring[n & 1][s][slot][0]);
-        k[s] = ml.rhs(Ml::stage(e, Yo));
+        k[s] = ml.rhs(Ml::stage(e[s], Yo));
       }
       yo = sp_advance<METHOD>(yo, dt, k[0], k[1], k[2], k[3]);
       if (live) Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
@@ -615,13 +618,16 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         // ---- recompute the learned stage derivatives
         typename Ml::Stage Y[4];
         Own so[4];
+        float4 e[4];  // all four expert stage states up front: one LDS round trip per step instead of one per stage
+#pragma unroll
+        for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
 #pragma unroll
         for (int s = 0; s < 4; ++s) so[s] = vsplat<Own>(0.f);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           const Own Yo = sp_stage_state<METHOD>(s, yo, dt, so[0], so[1], so[2]);
-          const float4 e = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
-          Y[s] = Ml::stage(e, Yo);
+          Y[s] = Ml::stage(e[s], Yo);
           so[s] = ml.rhs(Y[s]);
         }
         // ---- adjoint of the stages
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(64) void split_fold_kernel(const float* __restrict_
 }
 
 template <int D, int METHOD, bool ABLATE, bool NEED_TH, bool TAPE>
-__global__ __launch_bounds__(256) void split_bwd_kernel(SplitBwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_bwd_kernel(SplitBwdArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
   if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true, TAPE>(a);
   else if (hill2) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, false, TAPE>(a);
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(256) void split_bwd_kernel(SplitBwdArgs a) {
 }
 
 template <int D, int METHOD, bool ABLATE, bool TAPE>
-__global__ __launch_bounds__(256) void split_fwd_kernel(SplitArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_fwd_kernel(SplitArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
   if (hill2 && a.K == 1) split_fwd_body<D, METHOD, ABLATE, true, true, TAPE>(a);
   else if (hill2) split_fwd_body<D, METHOD, ABLATE, true, false, TAPE>(a);
