@@ -105,9 +105,11 @@ def cpu_baseline(inp, wb, n_sample=2000, reps=3):
                       % (n_sample, N_PER_GPU, T, D, reps, med)}
 
 
-def pmc_traffic():
+def pmc_traffic(tape=True):
     """HBM bytes per launch of the dominant (backward) kernel from the committed rocprofv3 --pmc passes
-    (profiles/*_pmc_summary.json, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); None if absent."""
+    (profiles/*_pmc_summary.json, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); None if absent.
+    The tape variant of the kernel (template arguments end in `true, true>`) reads the forward's stage tape on top of
+    the algorithmic bytes; the newest summary that holds the variant being timed wins."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
@@ -118,6 +120,10 @@ def pmc_traffic():
         for k, v in d.items():
             if ("split_bwd_kernel<12" in k or "rk_bwd_kernel<12" in k) and "hbm_bytes_per_launch" in v:
                 if best is not None and "split" in best.get("kernel", "") and "split" not in k:
+                    continue
+                if "split" in k and (k.count(",") == 4) and (k.rstrip().endswith("true, true>") != tape):
+                    continue
+                if "split" in k and k.count(",") < 4 and tape:
                     continue
                 best = {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "kernel": k}
     return best
@@ -265,10 +271,15 @@ def main():
                                  "achieved": plan.fwd_bytes / fwd_s / 1e9},
                          "step_frac": (plan.fwd_bytes + plan.bwd_bytes) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
-        tr = pmc_traffic()
+        tr = pmc_traffic(tape=not args.no_tape)
         if tr is not None:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
+        if not args.no_tape:
+            # deliberate recompute <-> traffic trade: the forward leaves the 3 intermediate expert stage
+            # states of every step (16 B each) and the backward reads them back instead of re-integrating
+            out["roofline"]["tape_bytes_per_launch"] = (T - 1) * 3 * N_PER_GPU * 16
+            out["config"]["stage_tape"] = True
         if args.full_step:
             ms_full = full_step_ms(dev)
             out["full_training_step"] = {"ms": ms_full, "trajectories_per_s": N_PER_GPU / ms_full * 1e3,

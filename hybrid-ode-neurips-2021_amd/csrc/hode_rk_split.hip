@@ -256,7 +256,7 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
           const f2 Yb = sp_stage_state<METHOD>(s, yb, dt, kb[0], kb[1], kb[2]);
           if (slot < kSplitPatients) *reinterpret_cast<float4*>(&ring[it & 1][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
           if constexpr (TAPE) {
-            if (s >= 1 && live)
+            if (s >= 1)
               *reinterpret_cast<float4*>(tape_it + ((unsigned)(s - 1) * (unsigned)a.B * 4u + lane_t)) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
           }
           const float Y[4] = {Ya.x, Ya.y, Yb.x, Yb.y};
@@ -267,7 +267,8 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
         }
         ya = sp_advance<METHOD>(ya, dt, ka[0], ka[1], ka[2], ka[3]);
         yb = sp_advance<METHOD>(yb, dt, kb[0], kb[1], kb[2], kb[3]);
-        if (live) *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + lane_h) = make_float4(ya.x, ya.y, yb.x, yb.y);
+        // unpredicated (see the learned waves' store): spare lanes hold bit-identical copies of a live patient
+        *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + lane_h) = make_float4(ya.x, ya.y, yb.x, yb.y);
       }
       t_cur = t_nx;
       t_nx = t_nn;
@@ -320,7 +321,9 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
         k[s] = ml.rhs(Ml::stage(e[s], Yo));
       }
       yo = sp_advance<METHOD>(yo, dt, k[0], k[1], k[2], k[3]);
-      if (live) Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
+      // no `if (live)`: a quad beyond the batch integrates a bit-identical copy of patient B-1 (p is clamped) and
+      // stores the same values to the same address -- cheaper than an exec-mask branch every step
+      Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
       t_a = t_b; t_b = t_c; t_c = t_d; t_d = t_e;
       __syncthreads();
     }
