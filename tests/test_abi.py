@@ -79,9 +79,35 @@ def test_workspace_query(lib):
     nblk = (10000 + 47) // 48
     n = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
     assert n % 256 == 0 and n >= nblk * (3 * (8 * 12 + 8) + 15) * 4
+    # HODE_FLAG_TAPE: forward and backward share one buffer = partials + 16 B per patient, interval and inner stage
+    d.flags, d.method = L.FLAG_TAPE, L.METHODS["rk4"]
+    nt = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
+    assert nt == n + 99 * 3 * 10000 * 16 and lib.hode_workspace_bytes(d, L.WS_RK_FWD) == nt
+    d.method = L.METHODS["midpoint"]
+    assert lib.hode_workspace_bytes(d, L.WS_RK_FWD) == n + 99 * 1 * 10000 * 16
+    d.method = L.METHODS["euler"]  # single stage: nothing to tape
+    assert lib.hode_workspace_bytes(d, L.WS_RK_FWD) == n
+    d.lanes_per_patient = 4  # layouts without a tape ignore the flag
+    assert lib.hode_workspace_bytes(d, L.WS_RK_FWD) == 0
+    d.flags, d.lanes_per_patient = 0, 0
     d.latent_dim = 20  # no split layout for D = 20: quad
     n20 = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
     assert n20 % ((16 * 20 + 16 + 15) * 4) == 0
+
+
+def test_tape_flag_needs_its_workspace(lib):
+    """hode_rk_fwd with HODE_FLAG_TAPE and no (or a short) workspace is an argument error, not a launch."""
+    import ctypes as C
+    from hode import _lib as L
+    d = L.new_solve_desc()
+    d.rhs_kind, d.method, d.batch, d.latent_dim, d.n_times, d.n_dose = 0, L.METHODS["rk4"], 96, 12, 5, 1
+    buf = (C.c_float * 64)()
+    ptr = C.addressof(buf)  # never dereferenced: the call must fail before any launch
+    d.t = d.y0 = d.dosage = d.dose_times = d.theta = d.w1 = d.b1 = d.h = ptr
+    d.flags = L.FLAG_TAPE
+    assert lib.hode_rk_fwd(d, None) == -4 and b"workspace" in lib.hode_last_error_string()
+    d.workspace, d.workspace_bytes = ptr, 128
+    assert lib.hode_rk_fwd(d, None) == -4
 
 
 def test_missing_library_fails_loudly(tmp_path):
