@@ -73,6 +73,15 @@ class ReadoutDesc(C.Structure):
     ]
 
 
+class CrpsDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_times", C.c_int32), ("batch", C.c_int32), ("n_members", C.c_int32),
+        ("latent_dim", C.c_int32), ("obs_dim", C.c_int32),
+        ("time_stride", C.c_int64), ("member_stride", C.c_int64), ("patient_stride", C.c_int64),
+        ("h", _fp), ("w", _fp), ("b", _fp), ("truth", _fp), ("crps", _fp), ("crps_sum", _fp),
+    ]
+
+
 #: every symbol include/hode.h declares: (name, restype, argtypes)
 EXPORTS = (
     ("hode_version", C.c_int, ()),
@@ -86,6 +95,7 @@ EXPORTS = (
     ("hode_dopri5_bwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
     ("hode_readout_workspace_bytes", C.c_size_t, (C.POINTER(ReadoutDesc),)),
     ("hode_readout_sse", C.c_int, (C.POINTER(ReadoutDesc), C.c_void_p)),
+    ("hode_ensemble_crps", C.c_int, (C.POINTER(CrpsDesc), C.c_void_p)),
     ("hode_lstm_fwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
     ("hode_lstm_bwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
 )

@@ -74,3 +74,119 @@ def variational_training_loop(niters, data_generator, model, batch_size, optimiz
     rank0_print("Time: {}".format(end - start))
     rank0_print("Overall best loss: {:.6f}".format(best_loss))
     return model, best_loss, end - start
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Evaluation (reference training_utils.py:100-279, :568-577).  Same signatures, prints and return values.  What changed:
+# the mc_itr posterior draws are integrated in ONE decoder call over a batch of mc_itr * B latents (the reference loops
+# mc_itr decoder calls) and scored by one `hode_ensemble_crps` launch that applies the linear readout on the fly (the
+# reference stacks (T', B, obs, mc_itr) and calls properscoring.crps_ensemble per element from three nested Python
+# loops).  The draws themselves are taken exactly as the reference takes them -- mc_itr consecutive
+# `encoder.reparameterize(*encoder_out)` calls -- so a seeded run sees the same random numbers.
+# ---------------------------------------------------------------------------------------------------------------------
+import numpy as np
+
+from hode import crps as _crps_mod
+
+_ensemble_crps = _crps_mod.ensemble_crps  # tests swap in the CPU oracle here; the product path never does
+
+
+def bootstrap_RMSE(err_sq):
+    if type(err_sq) == np.ndarray:
+        err_sq = torch.tensor(err_sq)
+    rmse_list = []
+    for _ in range(500):
+        new_err = err_sq[torch.randint(len(err_sq), err_sq.shape, device=err_sq.device)]
+        rmse_list.append(torch.sqrt(torch.mean(new_err)).item())
+    return np.std(np.array(rmse_list))
+
+
+def _posterior_scores(model, data, t0, mc_itr, real, expert_dim):
+    """One test chunk: point-estimate errors and ensemble CRPS.  Returns
+    (se_z0 (B,), sse_x (T', B), n_x (T', B), crps_z0 (B,) mean over expert dims, crps_x (T', B) mean over obs)."""
+    x, a, mask = data["measurements"][:t0], data["actions"][:t0], data["masks"][:t0]
+    z0 = data["latents"][0]
+    if real:
+        s = data["statics"][:t0]
+        encoder_out = model.encoder(x, torch.cat([a, s], dim=-1), mask)
+        z0_hat = encoder_out[0]
+        x_hat, _ = model.decoder(z0_hat, data["actions"], data["statics"])
+    else:
+        encoder_out = model.encoder(x, a, mask)
+        z0_hat = encoder_out[0]
+        x_hat, _ = model.decoder(z0_hat, data["actions"])
+    x_hat = x_hat[t0:, ...]
+    se_z0 = torch.sum((z0[:, :expert_dim] - z0_hat[:, :expert_dim]) ** 2, dim=1)
+    x_test, mask_test = data["measurements"][t0:], data["masks"][t0:]
+    sse_x = torch.sum((x_test - x_hat) ** 2 * mask_test, dim=2)
+    n_x = torch.sum(mask_test, dim=2)
+
+    # ---- posterior ensemble: mc_itr draws -> one batch of mc_itr * B latents (member-major)
+    M = int(mc_itr)
+    B, D = z0_hat.shape
+    z = torch.stack([model.encoder.reparameterize(*encoder_out) for _ in range(M)], dim=0)  # (M, B, D)
+    z_flat = z.reshape(M * B, D)
+    act = data["actions"].repeat(1, M, 1)
+    if real:
+        x_mc, _ = model.decoder(z_flat, act, data["statics"].repeat(1, M, 1))               # (T, M*B, obs)
+        crps_x = _ensemble_crps(x_mc[t0:].contiguous(), x_test, M)
+    else:
+        lin = model.decoder.output_function[0]
+        h_mc = model.decoder.latent(z_flat, act)                                            # (T, M*B, D)
+        crps_x = _ensemble_crps(h_mc[t0:], x_test, M, weight=lin.weight, bias=lin.bias)
+    crps_x = crps_x / x_test.shape[2]
+    crps_z0 = _ensemble_crps(z_flat.unsqueeze(0), z0[:, :expert_dim].unsqueeze(0).contiguous(), M)[0] / expert_dim
+    return se_z0, sse_x, n_x, crps_z0, crps_x
+
+
+def evaluate(model, data_generator, batch_size, t0, mc_itr=50, real=False):
+    with torch.no_grad():
+        total_rmse_z0, total_rmse_x, total_cprs_z0, total_cprs_x = [], [], [], []
+        for chunk in range(data_generator.test_size // batch_size):
+            data = data_generator.get_split("test", batch_size, chunk)
+            se_z0, sse_x, n_x, crps_z0, crps_x = _posterior_scores(model, data, t0, mc_itr, real, data_generator.expert_dim)
+            total_rmse_z0.append(se_z0)
+            total_rmse_x.append(sse_x.sum(dim=0) / n_x.sum(dim=0))
+            total_cprs_z0.append(crps_z0.cpu().numpy())
+            total_cprs_x.append(crps_x.mean(dim=0).cpu().numpy())
+
+        total_rmse_z0 = torch.cat(total_rmse_z0).cpu()
+        rmse_z0 = torch.sqrt(torch.mean(total_rmse_z0)).item()
+        rmse_z0_sd = bootstrap_RMSE(total_rmse_z0)
+
+        total_cprs_z0 = np.concatenate(total_cprs_z0)
+        cprs_z0 = np.mean(total_cprs_z0)
+        cprs_z0_sd = np.std(total_cprs_z0) / np.sqrt(len(total_cprs_z0))
+
+        total_rmse_x = torch.cat(total_rmse_x).cpu()
+        total_rmse_x = total_rmse_x[~torch.isnan(total_rmse_x)]
+        rmse_x = torch.sqrt(torch.mean(total_rmse_x)).item()
+        rmse_x_sd = bootstrap_RMSE(total_rmse_x)
+
+        total_cprs_x = np.concatenate(total_cprs_x)
+        cprs_x = np.mean(total_cprs_x)
+        cprs_x_sd = np.std(total_cprs_x) / np.sqrt(len(total_cprs_x))
+
+        print("rmse_z0,{:.4f},{:.4f}".format(rmse_z0, rmse_z0_sd))
+        print("rmse_x,{:.4f},{:.4f}".format(rmse_x, rmse_x_sd))
+        print("cprs_z0,{:.4f},{:.4f}".format(cprs_z0, cprs_z0_sd))
+        print("cprs_x,{:.4f},{:.4f}".format(cprs_x, cprs_x_sd))
+        return rmse_z0, rmse_z0_sd, cprs_z0, rmse_x, rmse_x_sd, cprs_x
+
+
+def evaluate_horizon(model, data_generator, batch_size, t0, mc_itr=10, real=False):
+    with torch.no_grad():
+        total_rmse_x, total_cprs_x = [], []
+        for chunk in range(data_generator.test_size // batch_size):
+            data = data_generator.get_split("test", batch_size, chunk)
+            _, sse_x, n_x, _, crps_x = _posterior_scores(model, data, t0, mc_itr, real, data_generator.expert_dim)
+            total_rmse_x.append((sse_x / n_x).cpu())          # T', B
+            total_cprs_x.append(crps_x.cpu().numpy())          # T', B
+
+        total_rmse_x = torch.cat(total_rmse_x, dim=1)
+        rmse_x = torch.sqrt(torch.nanmean(total_rmse_x, dim=1)).numpy()
+        rmse_x_sd = np.array([bootstrap_RMSE(total_rmse_x[i]) for i in range(rmse_x.shape[0])])
+        total_cprs_x = np.concatenate(total_cprs_x, axis=1)
+        cprs_x = np.mean(total_cprs_x, axis=1)
+        cprs_x_sd = np.std(total_cprs_x, axis=1) / np.sqrt(total_cprs_x.shape[1])
+        return {"rmse_x": rmse_x, "rmse_x_sd": rmse_x_sd, "cprs_x": cprs_x, "cprs_x_sd": cprs_x_sd}

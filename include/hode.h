@@ -193,6 +193,28 @@ typedef struct hode_readout_desc {
   size_t workspace_bytes;
 } hode_readout_desc;
 
+/* Ensemble CRPS of posterior samples (reference training_utils.py:147-176 / :247-264: mc_itr decoder passes stacked to
+ * (T', B, obs, M) and properscoring.crps_ensemble per element).  Member m of (time t, patient b) is the latent_dim-vector
+ * at h + t * time_stride + m * member_stride + b * patient_stride (floats); with w != NULL the scored value of component
+ * o is w[o] . vector + b[o] (the decoder's linear readout, never materialised), with w == NULL it is vector[o]. */
+typedef struct hode_crps_desc {
+  uint32_t struct_size;
+  int32_t n_times;        /* T' scored time points */
+  int32_t batch;          /* B patients */
+  int32_t n_members;      /* M ensemble members, 1..128 */
+  int32_t latent_dim;     /* width of a member vector, <= 128 */
+  int32_t obs_dim;        /* scored components per (time, patient), <= 128 */
+  int64_t time_stride;
+  int64_t member_stride;
+  int64_t patient_stride;
+  const float* h;
+  const float* w;         /* [obs][latent_dim] or NULL */
+  const float* b;         /* [obs] or NULL */
+  const float* truth;     /* [T'][B][obs] */
+  float* crps;            /* out [T'][B][obs], or NULL */
+  float* crps_sum;        /* out [T'][B]: sum over the obs components, or NULL */
+} hode_crps_desc;
+
 #define HODE_WS_RK_FWD 0
 #define HODE_WS_RK_BWD 1
 #define HODE_WS_DOPRI5_FWD 2
@@ -227,6 +249,9 @@ int hode_dopri5_bwd(const hode_solve_desc* desc, void* hip_stream);
 
 size_t hode_readout_workspace_bytes(const hode_readout_desc* desc);
 int hode_readout_sse(const hode_readout_desc* desc, void* hip_stream);
+
+/* CRPS = 1/M sum_m |x_m - y| - 1/M^2 sum_{i<j} |x_i - x_j| per scored element; one workgroup per (time, patient) */
+int hode_ensemble_crps(const hode_crps_desc* desc, void* hip_stream);
 
 int hode_lstm_fwd(const hode_lstm_desc* desc, void* hip_stream);
 int hode_lstm_bwd(const hode_lstm_desc* desc, void* hip_stream);

@@ -9,6 +9,8 @@ reference's latent-ODE forward / autograd-backward path:
                       restated from its published algorithm)
 * ``oracle.encoder``  masked reverse-time LSTM encoder (reference ``model.py:383-440``)
 * ``oracle.vi``       loss assembly        (reference ``model.py:1150-1214``)
+* ``oracle.evalmetrics``  ensemble CRPS (third-party ``properscoring``, absent: parity unpinned) and the per-chunk
+                      pieces of ``training_utils.evaluate`` (reference ``training_utils.py:100-201``)
 
 Who may import this package: ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` -- as the checker / timed CPU baseline only.
