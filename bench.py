@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--lanes", type=int, default=0, help="force lanes per patient (1|4), 0 = library default")
     ap.add_argument("--no-theta-grad", action="store_true", help="skip the 13 expert-constant gradients")
+    ap.add_argument("--sync-allreduce", action="store_true", help="N>1: wait for each step's gradient all-reduce before the next solve")
     ap.add_argument("--no-tape", action="store_true", help="backward re-integrates the expert stages instead of reading the forward's tape")
     ap.add_argument("--full-step", action="store_true", help="also time one full training step (encoder + loss) as an extra field")
     args = ap.parse_args()
@@ -208,20 +209,40 @@ def main():
     plan, inp, wb = build_plan(dev, rank, lanes=args.lanes, need_theta=not args.no_theta_grad, tape=not args.no_tape)
     use_graph = not args.no_graph
     log("rank %d: plan built (B=%d, T=%d, D=%d)" % (rank, N_PER_GPU, T, D))
+    overlap = dist is not None and use_graph and not args.sync_allreduce
     if use_graph:
-        plan.capture()
+        plan.capture(n_buckets=2 if overlap else 1)
         log("rank %d: graph captured" % rank)
 
+    # Data-parallel gradient exchange over xGMI: one RCCL all-reduce(AVG) of the flat bucket per step.  It is issued
+    # asynchronously on alternating buckets (one captured graph per bucket), so the exchange of step k runs on RCCL's stream
+    # while the solver kernels of step k+1 run -- in the full training step the same bucket is exchanged under the
+    # encoder's BPTT, which follows the solver backward.  Every exchange completes inside the timed region (fence()).
+    # --sync-allreduce serialises it instead (replay -> all-reduce -> replay).
+    works = [None, None]
+    state = {"k": 0}
+
     def step():
+        if overlap:
+            i = state["k"] & 1
+            if works[i] is not None:
+                works[i].wait()  # stream-side wait for the exchange issued two steps ago before its bucket is refilled
+            plan.replay(i)       # the graph captured for bucket i
+            works[i] = dist.all_reduce(plan.buckets[i], op=dist.ReduceOp.AVG, async_op=True)
+            state["k"] += 1
+            return
         if use_graph:
             plan.replay()
         else:
             plan.step()
         if dist is not None:
-            dist.all_reduce(plan.grad_flat, op=dist.ReduceOp.AVG)  # data-parallel gradient exchange over xGMI
+            dist.all_reduce(plan.grad_flat, op=dist.ReduceOp.AVG)
 
     def fence():
         if dist is not None:
+            for w in works:
+                if w is not None:
+                    w.wait()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -262,7 +283,9 @@ def main():
                                    "+ discrete-adjoint kernel (split expert/learned wave pipelines)" % (N_PER_GPU, T),
                        "patients_total": total, "launch": "hipGraph" if use_graph else "eager",
                        "lanes_per_patient": args.lanes or "auto", "theta_grad": not args.no_theta_grad,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "grad_exchange": None if dist is None else ("rccl all-reduce(AVG), async under the next solve" if overlap
+                                                                   else "rccl all-reduce(AVG), serialised")},
             "roofline": {"bound": "hbm", "kernel": "split_bwd_kernel<12, rk4> (adjoint kernel alone; the whole backward call incl. "
                                                       "accumulator memset and partial folds is bwd_call_us)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,

@@ -96,18 +96,34 @@ class RocheRKPlan:
         self.forward()
         return self.backward()
 
-    def capture(self):
-        """Capture forward + backward into one HIP graph; ``replay()`` then costs a single graph launch."""
+    def _point_grads_at(self, flat):
+        """Make ``flat`` the gradient bucket the backward writes ([w | b | theta], same layout as ``grad_flat``)."""
+        d = self.desc
+        d.grad_w1 = flat.data_ptr() if self.n_w else 0
+        d.grad_b1 = flat[self.n_w:].data_ptr() if self.n_b else 0
+        d.grad_theta = flat[self.n_w + self.n_b:].data_ptr()
+
+    def capture(self, n_buckets=1):
+        """Capture forward + backward into one HIP graph; ``replay()`` then costs a single graph launch.
+
+        ``n_buckets > 1`` captures one graph per gradient bucket (``self.buckets[i]``, ``replay(i)``): a data-parallel
+        caller alternates them so that the all-reduce of one bucket can run while the next step fills the other."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self.step()  # warm-up outside capture (module load, allocator)
         torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.step()
-        self._graph = g
-        return g
+        self.buckets = [self.grad_flat] + [torch.zeros_like(self.grad_flat) for _ in range(n_buckets - 1)]
+        self._graphs = []
+        for flat in self.buckets:
+            self._point_grads_at(flat)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self._graphs.append(g)
+        self._point_grads_at(self.grad_flat)
+        self._graph = self._graphs[0]
+        return self._graph
 
-    def replay(self):
-        self._graph.replay()
+    def replay(self, bucket=0):
+        self._graphs[bucket].replay()
