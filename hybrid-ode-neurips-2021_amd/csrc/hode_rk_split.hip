@@ -71,6 +71,14 @@ HODE_DEV float sp_stage_time(float t0, float t1, int perturb, int q) {
   return tq;
 }
 
+// The time grid staged in LDS (dynamic shared memory, T + 3 floats, the tail padded with t[T-1]): every wave reads its
+// 2-4 grid points per step with one or two ds_read2 next to the ring reads, instead of a global load that has to be
+// issued iterations ahead and rotated through registers (13 instructions per step on the learned waves).
+constexpr int kSplitMaxT = 8192;
+HODE_DEV void sp_stage_grid(float* __restrict__ tg, const float* __restrict__ t, int T) {
+  for (int i = threadIdx.x; i < T + 3; i += blockDim.x) tg[i] = t[min(i, T - 1)];
+}
+
 template <int METHOD>
 constexpr int sp_stages() { return METHOD == HODE_METHOD_EULER ? 1 : (METHOD == HODE_METHOD_MIDPOINT ? 2 : 4); }
 
@@ -213,11 +221,13 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
   // Dose(t_s) of the 4 stages of a step, written by the learned waves (stage q by quad lane q) one step ahead of the
   // expert wave: dring[n & 1] holds step n
   __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][4];
+  extern __shared__ float tg[];  // time grid, see sp_stage_grid
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int b0 = blockIdx.x * kSplitPatients;
   const RocheTheta th = load_theta(a.theta, ABLATE);
   const size_t row = (size_t)a.B * D;
+  sp_stage_grid(tg, a.t, a.T);  // visible after the first __syncthreads of either pipeline
 
   if (wave == 0) {
     // ------------------------------------------------------------------ expert pipeline: one patient per lane
@@ -236,14 +246,10 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       yb = pair2(v.z, v.w);
       if (live) *reinterpret_cast<float4*>(a.h + (size_t)p * D) = v;
     }
-    // the grid points are fetched two iterations before they are used: a load that is waited for on the spot costs a
-    // memory round trip per step
-    float t_cur = a.t[0], t_nx = a.t[min(1, a.T - 1)];
-    __syncthreads();  // the learned waves' prologue fills dring for steps 0 and 1
+    __syncthreads();  // the learned waves' prologue fills dring for steps 0 and 1; the grid is in LDS
     for (int it = 0; it < a.T; ++it) {
-      const float t_nn = a.t[min(it + 2, a.T - 1)];
       if (it + 1 < a.T) {
-        const float dt = t_nx - t_cur;
+        const float dt = tg[it + 1] - tg[it];
         const float4 dz = *reinterpret_cast<const float4*>(&dring[it & 1][rslot][0]);
         const float dose[4] = {dz.x, dz.y, dz.z, dz.w};
         float* __restrict__ tape_it = TAPE ? a.tape + (size_t)it * (NS - 1) * a.B * 4 : nullptr;
@@ -270,8 +276,6 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
         // unpredicated (see the learned waves' store): spare lanes hold bit-identical copies of a live patient
         *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + lane_h) = make_float4(ya.x, ya.y, yb.x, yb.y);
       }
-      t_cur = t_nx;
-      t_nx = t_nn;
       __syncthreads();
     }
     if (a.status) {
@@ -295,16 +299,15 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     auto dose_step = [&](int n, float t0, float t1) {  // lanes q >= NS write a value nobody reads
       dring[n & 1][slot][q] = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel).v;
     };
-    float t_a = a.t[0], t_b = a.t[min(1, a.T - 1)], t_c = a.t[min(2, a.T - 1)], t_d = a.t[min(3, a.T - 1)];
-    if (a.T >= 2) dose_step(0, t_a, t_b);
-    if (a.T >= 3) dose_step(1, t_b, t_c);
+    if (a.T >= 2) dose_step(0, a.t[0], a.t[1]);  // before the first barrier: straight from global memory
+    if (a.T >= 3) dose_step(1, a.t[1], a.t[2]);
     Own yo = Ml::load_own(a.y0 + (size_t)p * D, q);
     if (live) Ml::store_own(a.h + (size_t)p * D, q, yo);
     __syncthreads();  // doses of steps 0 and 1 are in place
     __syncthreads();  // iteration 0: the expert wave fills ring[0]
     for (int it = 1; it < a.T; ++it) {
       const int n = it - 1;
-      const float t_e = a.t[min(it + 3, a.T - 1)];  // t_a..t_d = t[it-1..it+2]
+      const float t_a = tg[it - 1], t_b = tg[it], t_c = tg[it + 1], t_d = tg[it + 2];  // padded past T-1
       const float dt = t_b - t_a;
       // the expert wave is at step `it` now and reads dring[it & 1]; past the last step this writes an unread slot
       dose_step(it + 1, t_c, t_d);
@@ -324,7 +327,6 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       // no `if (live)`: a quad beyond the batch integrates a bit-identical copy of patient B-1 (p is clamped) and
       // stores the same values to the same address -- cheaper than an exec-mask branch every step
       Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
-      t_a = t_b; t_b = t_c; t_c = t_d; t_d = t_e;
       __syncthreads();
     }
     if (a.status) {
@@ -410,12 +412,14 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   // Dose(t_s) [0..3] and dDose/dkel [4..7] of the 4 stages; written by the expert wave when it re-integrates, by the
   // learned waves (stage q by quad lane q) when the stage states come from the tape
   __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][8];
+  extern __shared__ float tg[];  // time grid, see sp_stage_grid
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int b0 = blockIdx.x * kSplitPatients;
   const RocheTheta th = load_theta(a.theta, ABLATE);
   const size_t row = (size_t)a.B * D;
   const int T = a.T;
+  sp_stage_grid(tg, a.t, a.T);  // visible after the __syncthreads that precedes both pipelines' loops
 
   if (wave == 0) {
     // ================================================================== expert wave
@@ -498,18 +502,14 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       fetch(T - 2);
       publish(T - 2, 0);
     }
-    float t_hi = a.t[T - 1], t_lo = a.t[max(T - 2, 0)];  // grid points of step m, fetched an iteration ahead
     __syncthreads();
     for (int k = 0; k < T; ++k) {
       if (T - 3 - k >= 0) fetch(T - 3 - k);
-      const float t_nx = a.t[max(T - 2 - k, 0)];
       if (k >= 1) {
         // ---- (b) adjoint of step m = T-1-k
         const int m = T - 1 - k;
         const int par = (k - 1) & 1;
-        const float dt = t_hi - t_lo;
-        t_hi = t_lo;
-        t_lo = t_nx;
+        const float dt = tg[m + 1] - tg[m];
         float Y[4][4];
         F4 cs[4];
         DoseVal dv[4];
@@ -596,17 +596,13 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       yo_nx = Ml::load_own(a.h + (size_t)m0 * row + (size_t)p * D, q);
       gh_nx = Ml::load_own(a.grad_h + (size_t)m0 * row + (size_t)p * D, q);
     }
-    float t_hi = a.t[T - 1], t_lo = a.t[max(T - 2, 0)];  // grid points of step m, fetched an iteration ahead
     __syncthreads();  // the expert wave's prologue fills ring 0
     for (int k = 0; k < T; ++k) {
-      const float t_nx = a.t[max(T - 3 - k, 0)];
       if (k <= T - 2) {
         const int m = T - 2 - k;
         const int par = k & 1;
-        const float t0 = t_lo, t1 = t_hi;
+        const float t0 = tg[m], t1 = tg[m + 1];
         const float dt = t1 - t0;
-        t_hi = t_lo;
-        t_lo = t_nx;
         const Own yo = yo_nx, gh = gh_nx;
         {
           const int mn = m >= 1 ? m - 1 : 0;  // clamped: the last prefetch is simply unused
@@ -742,9 +738,10 @@ namespace {
 template <int D, bool ABLATE>
 int split_method(const hode_solve_desc* d, const hode::SplitArgs& a, hipStream_t s) {
   const dim3 grid((d->batch + hode::kSplitPatients - 1) / hode::kSplitPatients), block(256);
+  const size_t lds = (size_t)(d->n_times + 3) * sizeof(float);  // the time grid (n_times <= kSplitMaxT)
 #define HODE_SPLIT_FWD(M)                                                                                 \
-  if (a.tape) hipLaunchKernelGGL((hode::split_fwd_kernel<D, M, ABLATE, true>), grid, block, 0, s, a);     \
-  else hipLaunchKernelGGL((hode::split_fwd_kernel<D, M, ABLATE, false>), grid, block, 0, s, a);
+  if (a.tape) hipLaunchKernelGGL((hode::split_fwd_kernel<D, M, ABLATE, true>), grid, block, lds, s, a);   \
+  else hipLaunchKernelGGL((hode::split_fwd_kernel<D, M, ABLATE, false>), grid, block, lds, s, a);
   switch (d->method) {
     case HODE_METHOD_EULER: HODE_SPLIT_FWD(HODE_METHOD_EULER) break;
     case HODE_METHOD_MIDPOINT: HODE_SPLIT_FWD(HODE_METHOD_MIDPOINT) break;
@@ -760,13 +757,14 @@ namespace {
 template <int D, bool ABLATE>
 int split_bwd_method(const hode_solve_desc* d, const hode::SplitBwdArgs& a, hipStream_t s) {
   const dim3 grid((d->batch + hode::kSplitPatients - 1) / hode::kSplitPatients), block(256);
+  const size_t lds = (size_t)(d->n_times + 3) * sizeof(float);  // the time grid (n_times <= kSplitMaxT)
 #define HODE_SPLIT_BWD(M)                                                                                        \
   if (d->need_theta_grad) {                                                                                      \
-    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, true>), grid, block, 0, s, a);      \
-    else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, false>), grid, block, 0, s, a);            \
+    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, true>), grid, block, lds, s, a);    \
+    else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, false>), grid, block, lds, s, a);          \
   } else {                                                                                                       \
-    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, true>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, false>), grid, block, 0, s, a);           \
+    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, true>), grid, block, lds, s, a);   \
+    else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, false>), grid, block, lds, s, a);         \
   }
   switch (d->method) {
     case HODE_METHOD_EULER: HODE_SPLIT_BWD(HODE_METHOD_EULER) break;
@@ -780,7 +778,8 @@ int split_bwd_method(const hode_solve_desc* d, const hode::SplitBwdArgs& a, hipS
 
 namespace hode {
 
-bool split_supported(const hode_solve_desc* d) { return d->latent_dim == 8 || d->latent_dim == 12; }
+// the grid lives in LDS: longer grids fall back to the quad layout
+bool split_supported(const hode_solve_desc* d) { return (d->latent_dim == 8 || d->latent_dim == 12) && d->n_times <= kSplitMaxT; }
 
 static size_t al256s(size_t x) { return (x + 255) / 256 * 256; }
 
