@@ -333,3 +333,30 @@ def test_split_tape_matches_recompute(D, method):
         outs.append((plan.h.clone(), gy0.clone(), flat.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_long_grids_fall_back_to_the_quad_layout():
+    """The split kernels keep the time grid in LDS (<= 8192 points); longer grids must silently take the quad layout."""
+    dev = _dev()
+    from hode.solver import pack_theta, roche_solve
+    from oracle.rhs import THETA_NAMES
+    N, D = 5, 12
+    inp, f = _case(N, 16, D, seed=3)
+    theta = pack_theta([getattr(f, n).detach().to(dev) for n in THETA_NAMES], dev)
+    w, b = f.ml_net[0].weight.detach().to(dev), f.ml_net[0].bias.detach().to(dev)
+    dosage = torch.full((N,), 2.0, device=dev)
+    times = torch.full((N, 1), 0.5, device=dev)
+    for T, same in ((8192, False), (8193, True)):
+        t = (torch.arange(T, dtype=torch.float32) * 1e-3).to(dev)
+        outs = []
+        for lanes in (0, 4):
+            y0 = inp["z0"].to(dev).requires_grad_(True)
+            h = roche_solve(y0, theta, w, b, t, dosage, times, method="rk4", lanes_per_patient=lanes)
+            h[-1].sum().backward()
+            outs.append((h.detach(), y0.grad.clone()))
+        assert torch.isfinite(outs[0][0]).all()
+        if same:  # T > 8192: `auto` IS the quad layout
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        else:
+            assert _rel(outs[0][0], outs[1][0]) < 1e-5 and _rel(outs[0][1], outs[1][1]) < 1e-4
