@@ -309,13 +309,13 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       const int n = it - 1;
       const float t_a = tg[it - 1], t_b = tg[it], t_c = tg[it + 1], t_d = tg[it + 2];  // padded past T-1
       const float dt = t_b - t_a;
-      // the expert wave is at step `it` now and reads dring[it & 1]; past the last step this writes an unread slot
-      dose_step(it + 1, t_c, t_d);
       Own k[4];
       float4 e[4];  // all four expert stage states up front: one LDS round trip per step instead of one per stage
 #pragma unroll
       for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&ring[n & 1][s][slot][0]);
       __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
+      // the expert wave is at step `it` now and reads dring[it & 1]; past the last step this writes an unread slot
+      dose_step(it + 1, t_c, t_d);
 #pragma unroll
       for (int s = 0; s < 4; ++s) k[s] = vsplat<Own>(0.f);
 #pragma unroll
@@ -609,11 +609,6 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
           yo_nx = Ml::load_own(a.h + (size_t)mn * row + (size_t)p * D, q);
           gh_nx = Ml::load_own(a.grad_h + (size_t)mn * row + (size_t)p * D, q);
         }
-        if constexpr (TAPE) {  // the expert wave adjoins this step next iteration: its doses, stage q by quad lane q
-          const DoseVal dq = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel);  // lanes q >= NS: unread
-          dring[par][slot][q] = dq.v;
-          if constexpr (NEED_TH) dring[par][slot][4 + q] = dq.dk;
-        }
         // ---- recompute the learned stage derivatives
         typename Ml::Stage Y[4];
         Own so[4];
@@ -621,6 +616,11 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
         __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
+        if constexpr (TAPE) {  // the expert wave adjoins this step next iteration: its doses, stage q by quad lane q
+          const DoseVal dq = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel);  // lanes q >= NS: unread
+          dring[par][slot][q] = dq.v;
+          if constexpr (NEED_TH) dring[par][slot][4 + q] = dq.dk;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) so[s] = vsplat<Own>(0.f);
 #pragma unroll
