@@ -104,6 +104,26 @@ HODE_DEV float quad_sum(float v) {
   return a + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xf, 0xf, true));
 }
 
+// DPP row rotations (a "row" = 16 lanes): plain VALU adds with a DPP operand, no LDS crossbar round trip like __shfl_xor
+template <int CTRL>
+HODE_DEV float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 4 lanes of a row that share (lane & 3), result in every lane of the row   (row_ror:4, row_ror:8)
+HODE_DEV float row_sum_stride4(float v) {
+  v += dpp_f32<0x124>(v);
+  v += dpp_f32<0x128>(v);
+  return v;
+}
+// sum over the 16 lanes of a row, result in every lane of the row   (row_ror:1, 2, 4, 8)
+HODE_DEV float row_sum(float v) {
+  v += dpp_f32<0x121>(v);
+  v += dpp_f32<0x122>(v);
+  v += dpp_f32<0x124>(v);
+  v += dpp_f32<0x128>(v);
+  return v;
+}
+
 // sum across the lanes of a wave that hold the same quad position (xor over lane bits 2..5), result everywhere
 HODE_DEV float wave_sum_stride4(float v) {
 #pragma unroll

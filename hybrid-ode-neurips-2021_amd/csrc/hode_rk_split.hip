@@ -412,6 +412,8 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   // Dose(t_s) [0..3] and dDose/dkel [4..7] of the 4 stages; written by the expert wave when it re-integrates, by the
   // learned waves (stage q by quad lane q) when the stage states come from the tape
   __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][8];
+  // epilogue: the 4 per-row (16-lane) partial sums of every gradient entry of a wave, summed across rows from here
+  __shared__ float red[4][4][M * D + M];
   extern __shared__ float tg[];  // time grid, see sp_stage_grid
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -546,11 +548,15 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       __syncthreads();
     }
     if (live) *reinterpret_cast<float4*>(a.grad_y0 + (size_t)p * D) = make_float4(lam.a.x, lam.a.y, lam.b.x, lam.b.y);
+    // theta partials: 16-lane row sums by DPP rotations, the 4 rows joined through LDS (in-order within the wave)
 #pragma unroll
     for (int i = 0; i < kNTheta; ++i) {
-      const float v = wave_sum(NEED_TH ? acc.dth[i] : 0.f);
-      if (lane == 0) a.part_th[(size_t)blockIdx.x * kNTheta + i] = v;
+      const float v = row_sum(NEED_TH ? acc.dth[i] : 0.f);
+      if ((lane & 15) == 0) red[0][lane >> 4][i] = v;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < kNTheta)
+      a.part_th[(size_t)blockIdx.x * kNTheta + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
   } else {
     // ================================================================== learned waves (quad layout, own components)
     const int q = lane & 3;
@@ -664,20 +670,27 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       __syncthreads();
     }
     if (live) Ml::store_own(a.grad_y0 + (size_t)p * D, q, lam);
+    // weight-gradient partials of this wave's 16 patients: sum over the 4 quads of a 16-lane row with two DPP
+    // rotations per entry, join the 4 rows through LDS, store the M*D + M entries with coalesced lanes
     float* out = a.part_ml + ((size_t)blockIdx.x * 3 + (wave - 1)) * (M * D + M);
+    const bool writer = (lane & 15) < 4;  // lane & 15 == q there
+    float* mine = &red[wave][lane >> 4][0];
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        const float v = wave_sum_stride4(Ml::dw_at(dw, r, i));
-        if (lane < 4) out[(lane * MR + r) * D + i] = v;
+        const float v = row_sum_stride4(Ml::dw_at(dw, r, i));
+        if (writer) mine[(q * MR + r) * D + i] = v;
       }
       float dbr;
       if constexpr (MR == 2) dbr = r == 0 ? db.x : db.y;
       else dbr = db;
-      const float vb = wave_sum_stride4(dbr);
-      if (lane < 4) out[M * D + lane * MR + r] = vb;
+      const float vb = row_sum_stride4(dbr);
+      if (writer) mine[M * D + q * MR + r] = vb;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int c = lane; c < M * D + M; c += 64)
+      out[c] = (red[wave][0][c] + red[wave][1][c]) + (red[wave][2][c] + red[wave][3][c]);
   }
 }
 
