@@ -102,6 +102,11 @@ HODE_DEV V sp_advance(V y, float dt, V k1, V k2, V k3, V k4) {
   else return vfma((k1 + 3.0f * (k2 + k3)) + k4, vsplat<V>(dt * 0.125f), y);
 }
 
+// The time loops are unrolled by two by hand (a lambda per iteration, instantiated for both ring parities): every ring
+// offset becomes an immediate instead of s_and / s_mul / v_add per ring and iteration.  (The compiler cannot unroll a loop
+// with a barrier and a run-time trip count itself.)
+template <int V> struct IC { static constexpr int value = V; };
+
 template <int MR> struct OwnSel { typedef float type; };
 template <> struct OwnSel<2> { typedef f2 type; };
 
@@ -247,10 +252,11 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       if (live) *reinterpret_cast<float4*>(a.h + (size_t)p * D) = v;
     }
     __syncthreads();  // the learned waves' prologue fills dring for steps 0 and 1; the grid is in LDS
-    for (int it = 0; it < a.T; ++it) {
+    auto e_iter = [&](int it, auto PAR) {
+      constexpr int par = decltype(PAR)::value;  // == it & 1
       if (it + 1 < a.T) {
         const float dt = tg[it + 1] - tg[it];
-        const float4 dz = *reinterpret_cast<const float4*>(&dring[it & 1][rslot][0]);
+        const float4 dz = *reinterpret_cast<const float4*>(&dring[par][rslot][0]);
         const float dose[4] = {dz.x, dz.y, dz.z, dz.w};
         float* __restrict__ tape_it = TAPE ? a.tape + (size_t)it * (NS - 1) * a.B * 4 : nullptr;
         f2 ka[4], kb[4];
@@ -260,7 +266,7 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
         for (int s = 0; s < NS; ++s) {
           const f2 Ya = sp_stage_state<METHOD>(s, ya, dt, ka[0], ka[1], ka[2]);
           const f2 Yb = sp_stage_state<METHOD>(s, yb, dt, kb[0], kb[1], kb[2]);
-          if (slot < kSplitPatients) *reinterpret_cast<float4*>(&ring[it & 1][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
+          if (slot < kSplitPatients) *reinterpret_cast<float4*>(&ring[par][s][slot][0]) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
           if constexpr (TAPE) {
             if (s >= 1)
               *reinterpret_cast<float4*>(tape_it + ((unsigned)(s - 1) * (unsigned)a.B * 4u + lane_t)) = make_float4(Ya.x, Ya.y, Yb.x, Yb.y);
@@ -277,6 +283,10 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
         *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + lane_h) = make_float4(ya.x, ya.y, yb.x, yb.y);
       }
       __syncthreads();
+    };
+    for (int it = 0; it < a.T; it += 2) {
+      e_iter(it, IC<0>{});
+      if (it + 1 < a.T) e_iter(it + 1, IC<1>{});
     }
     if (a.status) {
       const bool bad = !(vfinite(ya) && vfinite(yb));
@@ -296,8 +306,8 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     ds.taus = a.dose_times + (size_t)p * a.K;
     ds.tau0 = K1 ? ds.taus[0] : 0.f;
     // Dose(t) at stage q of step n for the expert wave (it reads all four stages with one ds_read_b128)
-    auto dose_step = [&](int n, float t0, float t1) {  // lanes q >= NS write a value nobody reads
-      dring[n & 1][slot][q] = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel).v;
+    auto dose_step = [&](int parity, float t0, float t1) {  // step n goes to dring[n & 1]; lanes q >= NS: unread
+      dring[parity][slot][q] = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel).v;
     };
     if (a.T >= 2) dose_step(0, a.t[0], a.t[1]);  // before the first barrier: straight from global memory
     if (a.T >= 3) dose_step(1, a.t[1], a.t[2]);
@@ -305,17 +315,18 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     if (live) Ml::store_own(a.h + (size_t)p * D, q, yo);
     __syncthreads();  // doses of steps 0 and 1 are in place
     __syncthreads();  // iteration 0: the expert wave fills ring[0]
-    for (int it = 1; it < a.T; ++it) {
+    auto m_iter = [&](int it, auto PAR) {
+      constexpr int par = decltype(PAR)::value;  // == (it - 1) & 1 == (it + 1) & 1
       const int n = it - 1;
       const float t_a = tg[it - 1], t_b = tg[it], t_c = tg[it + 1], t_d = tg[it + 2];  // padded past T-1
       const float dt = t_b - t_a;
       Own k[4];
       float4 e[4];  // all four expert stage states up front: one LDS round trip per step instead of one per stage
 #pragma unroll
-      for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&ring[n & 1][s][slot][0]);
+      for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&ring[par][s][slot][0]);
       __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
       // the expert wave is at step `it` now and reads dring[it & 1]; past the last step this writes an unread slot
-      dose_step(it + 1, t_c, t_d);
+      dose_step(par, t_c, t_d);
 #pragma unroll
       for (int s = 0; s < 4; ++s) k[s] = vsplat<Own>(0.f);
 #pragma unroll
@@ -328,6 +339,10 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       // stores the same values to the same address -- cheaper than an exec-mask branch every step
       Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
       __syncthreads();
+    };
+    for (int it = 1; it < a.T; it += 2) {
+      m_iter(it, IC<0>{});
+      if (it + 1 < a.T) m_iter(it + 1, IC<1>{});
     }
     if (a.status) {
       if (!vfinite(yo) && live) atomicOr(a.status, HODE_STATUS_NONFINITE);
@@ -505,12 +520,12 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       publish(T - 2, 0);
     }
     __syncthreads();
-    for (int k = 0; k < T; ++k) {
+    auto e_iter = [&](int k, auto PAR) {
+      constexpr int par = decltype(PAR)::value;  // == (k - 1) & 1 == (k + 1) & 1: the buffer (b) reads and (a) refills
       if (T - 3 - k >= 0) fetch(T - 3 - k);
       if (k >= 1) {
         // ---- (b) adjoint of step m = T-1-k
         const int m = T - 1 - k;
-        const int par = (k - 1) & 1;
         const float dt = tg[m + 1] - tg[m];
         float Y[4][4];
         F4 cs[4];
@@ -544,8 +559,12 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         lam.b = vfma(lv, pair2(g4.z, g4.w), lam.b);
       }
       // ---- (a) stage states of step T-3-k for the learned waves' next iteration
-      if (T - 3 - k >= 0) publish(T - 3 - k, (k + 1) & 1);
+      if (T - 3 - k >= 0) publish(T - 3 - k, par);
       __syncthreads();
+    };
+    for (int k = 0; k < T; k += 2) {
+      e_iter(k, IC<1>{});
+      if (k + 1 < T) e_iter(k + 1, IC<0>{});
     }
     if (live) *reinterpret_cast<float4*>(a.grad_y0 + (size_t)p * D) = make_float4(lam.a.x, lam.a.y, lam.b.x, lam.b.y);
     // theta partials: 16-lane row sums by DPP rotations, the 4 rows joined through LDS (in-order within the wave)
@@ -603,10 +622,10 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       gh_nx = Ml::load_own(a.grad_h + (size_t)m0 * row + (size_t)p * D, q);
     }
     __syncthreads();  // the expert wave's prologue fills ring 0
-    for (int k = 0; k < T; ++k) {
+    auto m_iter = [&](int k, auto PAR) {
+      constexpr int par = decltype(PAR)::value;  // == k & 1
       if (k <= T - 2) {
         const int m = T - 2 - k;
-        const int par = k & 1;
         const float t0 = tg[m], t1 = tg[m + 1];
         const float dt = t1 - t0;
         const Own yo = yo_nx, gh = gh_nx;
@@ -668,6 +687,10 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         lam = vfma(lv, gh, lam);
       }
       __syncthreads();
+    };
+    for (int k = 0; k < T; k += 2) {
+      m_iter(k, IC<0>{});
+      if (k + 1 < T) m_iter(k + 1, IC<1>{});
     }
     if (live) Ml::store_own(a.grad_y0 + (size_t)p * D, q, lam);
     // weight-gradient partials of this wave's 16 patients: sum over the 4 quads of a 16-lane row with two DPP
