@@ -168,20 +168,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
 #pragma unroll
       for (int c = 0; c < NT; ++c) acc[tt][c] = bias[tt];
 
-    // software-pipelined weight fragments: group q+1 is loaded while group q feeds the matrix pipe
-    f32x4 wa[TPW], wb[TPW];
-#pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) wa[tt] = wbase[(size_t)tt * 64];
-    for (int q = 0; q < p.KQ4; ++q) {
-      const bool has_next = q + 1 < p.KQ4;
-      if (has_next) {
-#pragma unroll
-        for (int tt = 0; tt < TPW; ++tt) wb[tt] = wbase[((size_t)(q + 1) * TPW + tt) * 64];
-      }
-      const int kq_lim = min(4, p.Kq - 4 * q);
+    // software-pipelined weight fragments: group q+1 is loaded while group q feeds the matrix pipe.  The loop over
+    // full groups (4 k-quads each) is branch-free; the partial last group is peeled -- with a conditional per k-quad
+    // inside the loop the waitcnt pass falls back to vmcnt(0) at every quad, i.e. it waits for the prefetch it has just
+    // issued (one L2 round trip per group, 16 per step).
+    auto quads = [&](const f32x4 (&wf)[TPW], int q, int kk_begin, int kk_end) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        if (kk < kq_lim) {
+        if (kk >= kk_begin && kk < kk_end) {
           const float* rowp = cur + (size_t)(4 * (4 * q + kk) + g) * LD + pc;
           float bf[NT];
 #pragma unroll
@@ -190,14 +184,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
           for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
             for (int c = 0; c < NT; ++c)
-              acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tt][kk], bf[c], acc[tt][c], 0, 0, 0);
+              acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][kk], bf[c], acc[tt][c], 0, 0, 0);
         }
       }
-      if (has_next) {
+    };
+    auto load_group = [&](f32x4 (&wf)[TPW], int q) {
 #pragma unroll
-        for (int tt = 0; tt < TPW; ++tt) wa[tt] = wb[tt];
-      }
+      for (int tt = 0; tt < TPW; ++tt) wf[tt] = wbase[((size_t)q * TPW + tt) * 64];
+    };
+    f32x4 wa[TPW], wb[TPW];
+    const int n_full = p.Kq >> 2;        // groups with all 4 k-quads
+    const int tail = p.Kq & 3;           // k-quads of the last, partial group (its fragments are zero padded)
+    const int n_groups = n_full + (tail ? 1 : 0);
+    load_group(wa, 0);
+    for (int q = 0; q < n_full; ++q) {
+      load_group(wb, min(q + 1, n_groups - 1));  // clamped: the last prefetch may be a repeat, never out of bounds
+      quads(wa, q, 0, 4);
+#pragma unroll
+      for (int tt = 0; tt < TPW; ++tt) wa[tt] = wb[tt];
     }
+    if (tail) quads(wa, n_full, 0, tail);
 
     // cell update: lane (g, pc) holds gates i,f,g,o of unit u = (w*TPW + tt)*4 + g for patient 16c + pc
     float* tp = p.tape ? p.tape + (((size_t)t * gridDim.x + blockIdx.x) * 4 + w) * TPW * NT * 5 * 64 + l : nullptr;
