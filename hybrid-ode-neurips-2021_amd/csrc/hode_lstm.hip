@@ -287,7 +287,7 @@ __global__ void lstm_pack_hh_kernel(const float* __restrict__ w_hh, float* __res
 }
 
 template <int NT, int TPW>
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(LstmBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BT = 16 * NT;
   constexpr int Hp = 16 * TPW;
@@ -315,15 +315,54 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs p) {
       carry_c[tt][c] = 0.f;
     }
   }
+  // wave-uniform bases (SGPRs) + one 32-bit lane offset: with per-lane 64-bit pointers the compiler hoists one address
+  // pair per fragment out of the step loop (100 pairs for TPW = 10) and spills them
+  const int wu = __builtin_amdgcn_readfirstlane(w);
   const size_t tape_step = (size_t)gridDim.x * 4 * TPW * NT * 5 * 64;
-  const size_t tape_blk = ((size_t)blockIdx.x * 4 + w) * TPW * NT * 5 * 64 + l;
-  const f32x4* whb = reinterpret_cast<const f32x4*>(p.whp) + (size_t)w * TPW * TPW * 64 + l;
+  const size_t tape_blk = ((size_t)blockIdx.x * 4 + wu) * TPW * NT * 5 * 64;
+  const f32x4* whb = reinterpret_cast<const f32x4*>(p.whp) + (size_t)wu * TPW * TPW * 64;
+
+  // Operands of one (step, unit tile): the step's activated gates and cell state and the previous step's cell state
+  // and output gate for NT patient columns, plus the TPW weight fragments the tile's MFMAs read.  They are fetched ONE
+  // TILE AHEAD into the other register set (the tile loop is fully unrolled, so the sets alternate by renaming): a load
+  // that is consumed by the next instruction costs an HBM / L2 round trip per tile, which is what bound this kernel
+  // (10 tiles x 3 serial waits per step, 61 us per step against 16 us of MFMA time).
+  struct TapeOps { float gi[NT], gf[NT], gg[NT], go[NT], cn[NT], cp[NT], op[NT]; };
+  auto step_ptrs = [&](int s, const float*& tc, const float*& tpv) {
+    const int t = p.reverse ? p.T - 1 - s : s;
+    const int t_prev = p.reverse ? t + 1 : t - 1;  // time index processed one step earlier in the forward sweep
+    tc = p.tape + (size_t)t * tape_step + tape_blk;
+    tpv = (s > 0) ? p.tape + (size_t)t_prev * tape_step + tape_blk : tc;  // s == 0: dummy reads, masked by has_prev
+  };
+  auto load_ops = [&](TapeOps& o, f32x4 (&wf)[TPW], const f32x4* wh, const float* tc, const float* tpv, int tt) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const float* q5 = tc + (tt * NT + c) * 5 * 64;   // uniform
+      const float* p5 = tpv + (tt * NT + c) * 5 * 64;
+      o.gi[c] = q5[l]; o.gf[c] = q5[64 + l]; o.gg[c] = q5[128 + l]; o.go[c] = q5[192 + l]; o.cn[c] = q5[256 + l];
+      o.cp[c] = p5[256 + l]; o.op[c] = p5[192 + l];
+    }
+#pragma unroll
+    for (int mt = 0; mt < TPW; ++mt) wf[mt] = (wh + (tt * TPW + mt) * 64)[l];
+  };
+  TapeOps oa, ob;
+  f32x4 wa[TPW], wb[TPW];
+  {
+    const float *tc0, *tpv0;
+    step_ptrs(p.T - 1, tc0, tpv0);
+    load_ops(oa, wa, whb, tc0, tpv0, 0);
+  }
 
   for (int s = p.T - 1; s >= 0; --s) {
     const int t = p.reverse ? p.T - 1 - s : s;
-    const int t_prev = p.reverse ? t + 1 : t - 1;   // time index processed one step earlier in the forward sweep
-    const float* tc = p.tape + (size_t)t * tape_step + tape_blk;
-    const float* tpv = (s > 0) ? p.tape + (size_t)t_prev * tape_step + tape_blk : nullptr;
+    const float *tc, *tpv, *tc_n, *tpv_n;
+    step_ptrs(s, tc, tpv);
+    step_ptrs(s > 0 ? s - 1 : 0, tc_n, tpv_n);  // next step's first tile (s == 0: a harmless repeat)
+    const float has_prev = s > 0 ? 1.0f : 0.0f;
+    // re-materialise the (SGPR) weight base every step: otherwise the TPW * TPW fragment addresses are hoisted out of
+    // the step loop as per-lane 64-bit pointers, spilled, and reloaded with a wait in front of every load
+    const f32x4* wh = whb;
+    asm volatile("" : "+s"(wh));
 
     f32x4 acc[TPW][NT];
 #pragma unroll
@@ -331,23 +370,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs p) {
 #pragma unroll
       for (int c = 0; c < NT; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
+    auto tile = [&](int tt, const TapeOps& o, const f32x4 (&wf)[TPW], TapeOps& o_nx, f32x4 (&wf_nx)[TPW]) {
+      if (tt + 1 < TPW) load_ops(o_nx, wf_nx, wh, tc, tpv, tt + 1);
+      else load_ops(o_nx, wf_nx, wh, tc_n, tpv_n, 0);
       const int u = (w * TPW + tt) * 4 + g;
-      f32x4 wf[TPW];
-#pragma unroll
-      for (int mt = 0; mt < TPW; ++mt) wf[mt] = whb[((size_t)tt * TPW + mt) * 64];
       float dgr[NT][4];
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
-        const float* q5 = tc + (size_t)(tt * NT + c) * 5 * 64;
-        const float gi = q5[0], gf = q5[64], gg = q5[128], go = q5[192], cn = q5[256];
-        float c_prev = 0.f, h_prev = 0.f;
-        if (tpv) {
-          const float* p5 = tpv + (size_t)(tt * NT + c) * 5 * 64;
-          c_prev = p5[256];
-          h_prev = p5[192] * tanh_f32(c_prev);
-        }
+        const float gi = o.gi[c], gf = o.gf[c], gg = o.gg[c], go = o.go[c], cn = o.cn[c];
+        const float c_prev = has_prev * o.cp[c];
+        const float h_prev = has_prev * (o.op[c] * tanh_f32(c_prev));
         const float tcn = tanh_f32(cn);
         const float dh = carry_h[tt][c];
         const float dc = __builtin_fmaf(dh * go, __builtin_fmaf(-tcn, tcn, 1.0f), carry_c[tt][c]);
@@ -370,22 +402,43 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs p) {
 #pragma unroll
           for (int c = 0; c < NT; ++c)
             acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[mt][r], dgr[c][r], acc[mt][c], 0, 0, 0);
+    };
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      if (tt & 1) tile(tt, ob, wb, oa, wa);
+      else tile(tt, oa, wa, ob, wb);
+    }
+    if constexpr (TPW & 1) {  // odd tile count: the next step's first tile landed in the other set
+      oa = ob;
+#pragma unroll
+      for (int mt = 0; mt < TPW; ++mt) wa[mt] = wb[mt];
     }
     __syncthreads();
-    // coalesced row-major stores of this step's dG and h_prev tiles
+    // coalesced row-major stores of this step's dG and h_prev tiles.  Wave w stores patients w, w+4, ...; the loops run
+    // over (patient, gate, unit) explicitly -- a flat index would need two integer divisions per element, which made
+    // this transposition the longest phase of the step (120 iterations x ~70 instructions per thread).
     {
       float* gdst = p.grad_gates + ((size_t)t * p.B + b0) * 4 * H;
-      const int n4 = 4 * H;
-      for (int e = tid; e < nvalid * n4; e += 256) {
-        const int b = e / n4, col = e - b * n4;
-        const int r = col / H, u = col - r * H;
-        gdst[e] = dgt[(size_t)b * LDG + r * Hp + u];
-      }
       const int HA = H + p.AD;
       float* hdst = p.h_prev + ((size_t)t * p.B + b0) * HA;
-      for (int e = tid; e < nvalid * HA; e += 256) {
-        const int b = e / HA, u = e - b * HA;
-        hdst[e] = u < H ? hT[(size_t)b * LDH + u] : p.a[((size_t)t * p.B + b0 + b) * p.AD + (u - H)];
+      const float* asrc = p.a ? p.a + ((size_t)t * p.B + b0) * p.AD : nullptr;
+      for (int b = w; b < nvalid; b += 4) {
+        const float* drow = dgt + (size_t)b * LDG;
+        float* grow = gdst + (size_t)b * 4 * H;
+        if ((H & 3) == 0) {  // 16-byte rows: one ds_read_b128 + one global_store_dwordx4 per 4 gate values
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            for (int u = 4 * l; u < H; u += 256)
+              *reinterpret_cast<f32x4*>(grow + r * H + u) = *reinterpret_cast<const f32x4*>(drow + r * Hp + u);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            for (int u = l; u < H; u += 64) grow[r * H + u] = drow[r * Hp + u];
+        }
+        const float* hrow = hT + (size_t)b * LDH;
+        float* hd = hdst + (size_t)b * HA;
+        for (int u = l; u < H; u += 64) hd[u] = hrow[u];
+        for (int u = l; u < p.AD; u += 64) hd[H + u] = asrc[(size_t)b * p.AD + u];
       }
     }
     __syncthreads();
