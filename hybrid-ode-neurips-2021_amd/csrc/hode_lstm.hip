@@ -172,19 +172,30 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
     // full groups (4 k-quads each) is branch-free; the partial last group is peeled -- with a conditional per k-quad
     // inside the loop the waitcnt pass falls back to vmcnt(0) at every quad, i.e. it waits for the prefetch it has just
     // issued (one L2 round trip per group, 16 per step).
+    // B fragments (one LDS row per patient column) are read one k-quad ahead: read-then-use in front of every 30-MFMA
+    // block would expose the LDS latency 61 times per step
+    float bf[NT];
+    const int last_quad = p.Kq - 1;
+    auto read_b = [&](float (&dst)[NT], int quad) {
+      const float* rowp = cur + (size_t)(4 * min(quad, last_quad) + g) * LD + pc;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) dst[c] = rowp[16 * c];
+    };
+    read_b(bf, 0);
     auto quads = [&](const f32x4 (&wf)[TPW], int q, int kk_begin, int kk_end) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         if (kk >= kk_begin && kk < kk_end) {
-          const float* rowp = cur + (size_t)(4 * (4 * q + kk) + g) * LD + pc;
-          float bf[NT];
-#pragma unroll
-          for (int c = 0; c < NT; ++c) bf[c] = rowp[16 * c];
+          float bn[NT];
+          read_b(bn, 4 * q + kk + 1);
+          __builtin_amdgcn_sched_barrier(0);  // keep the read HERE: the scheduler would sink it next to its use
 #pragma unroll
           for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
             for (int c = 0; c < NT; ++c)
               acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][kk], bf[c], acc[tt][c], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bf[c] = bn[c];
         }
       }
     };
