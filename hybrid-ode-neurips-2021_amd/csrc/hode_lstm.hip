@@ -277,7 +277,7 @@ struct LstmBwdArgs {
   const float* __restrict__ whp;       // packed W_hh^T fragments [4][TPW(tau)][TPW(mt)][64][4]
   const float* __restrict__ grad_h_out;  // [B][H]
   float* __restrict__ grad_gates;      // [T][B][4H]
-  float* __restrict__ h_prev;          // [T][B][H + AD]: hidden state entering the step, then the action columns
+  float* __restrict__ h_prev;          // [T][B][H + AD + 1]: hidden state entering the step, the action columns, 1.0
   const float* __restrict__ a;         // [T][B][AD] or nullptr
   int T, B, H, Hp, LD, reverse, AD;
 };
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // this transposition the longest phase of the step (120 iterations x ~70 instructions per thread).
     {
       float* gdst = p.grad_gates + ((size_t)t * p.B + b0) * 4 * H;
-      const int HA = H + p.AD;
+      const int HA = H + p.AD + 1;  // hidden state | action columns | 1.0 (the GEMM then yields the bias gradient too)
       float* hdst = p.h_prev + ((size_t)t * p.B + b0) * HA;
       const float* asrc = p.a ? p.a + ((size_t)t * p.B + b0) * p.AD : nullptr;
       for (int b = w; b < nvalid; b += 4) {
@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float* hd = hdst + (size_t)b * HA;
         for (int u = l; u < H; u += 64) hd[u] = hrow[u];
         for (int u = l; u < p.AD; u += 64) hd[H + u] = asrc[(size_t)b * p.AD + u];
+        if (l == 0) hd[H + p.AD] = 1.0f;
       }
     }
     __syncthreads();
@@ -647,9 +648,9 @@ int launch_bwd_tpw(const LstmGeom& G, const hode::LstmBwdArgs& a, hipStream_t s)
 }  // namespace
 
 // Backward of hode_lstm_fwd(save_tape = 1) with the SAME descriptor sizes and workspace: fills grad_gates[T][B][4H]
-// and h_prev[T][B][H + A] (hidden state entering each step, then the A action columns); the caller forms
-// grad_w_ih[:, :obs] = grad_gates^T (x*mask), [grad_w_hh | grad_w_ih[:, obs:]] = grad_gates^T h_prev and
-// grad_b_ih = grad_b_hh = column sums of grad_gates (plain GEMMs over K = T*B).
+// and h_prev[T][B][H + A + 1] (hidden state entering each step, the A action columns, a constant 1); the caller forms
+// grad_w_ih[:, :obs] = grad_gates^T (x*mask) and [grad_w_hh | grad_w_ih[:, obs:] | grad_b] = grad_gates^T h_prev
+// (plain GEMMs over K = T*B; the ones column makes the bias gradient a by-product instead of a third pass over dG).
 extern "C" int hode_lstm_bwd(const hode_lstm_desc* d, void* stream) {
   if (int e = check_lstm(d)) return e;
   if (!d->save_tape) return hode::fail(HODE_E_UNSUPPORTED, "hode_lstm_bwd needs the tape of a forward run with save_tape = 1");

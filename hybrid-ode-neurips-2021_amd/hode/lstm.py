@@ -58,7 +58,10 @@ def _splitk_tn(lhs, rhs):
             break
     if P == 1:
         return lhs.t() @ rhs
-    return torch.bmm(lhs.view(P, K // P, -1).transpose(1, 2), rhs.view(P, K // P, -1)).sum(0)
+    part = torch.bmm(lhs.view(P, K // P, -1).transpose(1, 2), rhs.view(P, K // P, -1))
+    # fold the P partial products with a (1 x P) GEMM: torch's strided sum(0) over this shape reads at ~0.3 TB/s
+    ones = torch.ones((1, P), device=part.device, dtype=part.dtype)
+    return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2])
 
 
 class _LstmEncode(torch.autograd.Function):
@@ -98,7 +101,7 @@ class _LstmEncode(torch.autograd.Function):
         gh = grad_h.to(torch.float32).contiguous()
         dgates = torch.empty((T, B, 4 * H), device=xc.device, dtype=torch.float32)
         ad = 0 if ac is None else ac.shape[-1]
-        hprev = torch.empty((T, B, H + ad), device=xc.device, dtype=torch.float32)
+        hprev = torch.empty((T, B, H + ad + 1), device=xc.device, dtype=torch.float32)
         d = _desc(xc, ac, mc, wi, wh, bi, bh, reverse, True)
         h_dummy = torch.empty(1, device=xc.device)
         d.h_out, d.c_out = h_dummy.data_ptr(), h_dummy.data_ptr()  # unused by the backward, must be non-NULL
@@ -109,10 +112,10 @@ class _LstmEncode(torch.autograd.Function):
         dg2 = dgates.view(T * B, 4 * H)
         xm = xc * mc if mc is not None else xc
         g_wih_x = _splitk_tn(dg2, xm.view(T * B, obs))
-        g_ha = _splitk_tn(dg2, hprev.view(T * B, H + ad))     # [grad_w_hh | action columns of grad_w_ih]
+        g_ha = _splitk_tn(dg2, hprev.view(T * B, H + ad + 1))  # [grad_w_hh | action columns of grad_w_ih | grad_b]
         g_whh = g_ha[:, :H].contiguous()
-        g_wih = g_wih_x if ad == 0 else torch.cat([g_wih_x, g_ha[:, H:]], dim=1)
-        g_b = dg2.sum(dim=0)
+        g_wih = g_wih_x if ad == 0 else torch.cat([g_wih_x, g_ha[:, H:H + ad]], dim=1)
+        g_b = g_ha[:, H + ad].contiguous()
         return None, None, None, g_wih, g_whh, g_b, g_b.clone(), None
 
 

@@ -166,8 +166,9 @@ typedef struct hode_lstm_desc {
   /* backward */
   const float* grad_h_out; /* [B][H] cotangent of h_out */
   float* grad_gates;   /* out [T][B][4H]: d loss / d pre-activation gates per step (feeds the weight-gradient GEMMs) */
-  float* h_prev;       /* out [T][B][H + (I - obs_dim)]: hidden state entering each step followed by the action
-                          columns of that step (the second GEMM operand: gives grad_w_hh and grad_w_ih[:, obs:]) */
+  float* h_prev;       /* out [T][B][H + (I - obs_dim) + 1]: hidden state entering each step, the action columns of that
+                          step, and a constant 1 (the second GEMM operand: grad_gates^T h_prev gives grad_w_hh,
+                          grad_w_ih[:, obs:] and, from the ones column, grad_b_ih = grad_b_hh) */
   void* workspace;     /* >= hode_lstm_workspace_bytes: packed weights (+ tape when save_tape) */
   size_t workspace_bytes;
 } hode_lstm_desc;
