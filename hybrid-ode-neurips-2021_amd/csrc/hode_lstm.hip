@@ -113,30 +113,62 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
 #pragma unroll
     for (int c = 0; c < NT; ++c) cst[t][c] = hlast[t][c] = 0.f;
 
-  // x tile staging: the tile of one step is BT*OBS contiguous floats (patients are contiguous in [T][B][OBS])
-  constexpr int XPT = 20;  // staged elements per thread (covers BT*OBS <= 5120)
+  // x tile staging: the tile of one step is BT*OBS contiguous floats (patients are contiguous in [T][B][OBS]).
+  // OBS % 4 == 0 (every shipped shape): a thread owns 16-byte groups (patient b = idx % BT, group idx / BT) -- consecutive
+  // lanes are consecutive PATIENTS, so the k-major LDS writes are conflict free (the flat element order wrote a wave's
+  // 64 values into 2 banks) and no run-time division is needed; the 16-byte loads walk every cache line four times
+  // within the step, which L1 / L2 absorb.  Otherwise: flat element order, one division per element.
+  constexpr int XPT = 20;  // staged floats per thread (covers BT*OBS <= 5120)
   const int n_x = nvalid * p.OBS;
+  const bool vec4 = (p.OBS & 3) == 0;
+  const int Q4 = p.OBS >> 2;
   float xs[XPT];
   auto fetch_x = [&](int t) {
     const size_t base = ((size_t)t * p.B + b0) * p.OBS;
+    if (vec4) {
 #pragma unroll
-    for (int j = 0; j < XPT; ++j) {
-      const int e = tid + 256 * j;
-      float v = 0.f;
-      if (e < n_x) {
-        v = p.x[base + e];
-        if (p.mask) v *= p.mask[base + e];
+      for (int j = 0; j < XPT / 4; ++j) {
+        const int idx = tid + 256 * j;
+        const int b = idx % BT, i4 = idx / BT;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i4 < Q4 && b < nvalid) {
+          v = *reinterpret_cast<const f32x4*>(p.x + base + (size_t)b * p.OBS + 4 * i4);
+          if (p.mask) v *= *reinterpret_cast<const f32x4*>(p.mask + base + (size_t)b * p.OBS + 4 * i4);
+        }
+        xs[4 * j] = v[0]; xs[4 * j + 1] = v[1]; xs[4 * j + 2] = v[2]; xs[4 * j + 3] = v[3];
       }
-      xs[j] = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < XPT; ++j) {
+        const int e = tid + 256 * j;
+        float v = 0.f;
+        if (e < n_x) {
+          v = p.x[base + e];
+          if (p.mask) v *= p.mask[base + e];
+        }
+        xs[j] = v;
+      }
     }
   };
   auto stage_x = [&](float* dst, int t) {
+    if (vec4) {
 #pragma unroll
-    for (int j = 0; j < XPT; ++j) {
-      const int e = tid + 256 * j;
-      if (e < n_x) {
-        const int b = e / p.OBS, i = e - b * p.OBS;
-        dst[i * LD + b] = xs[j];
+      for (int j = 0; j < XPT / 4; ++j) {
+        const int idx = tid + 256 * j;
+        const int b = idx % BT, i4 = idx / BT;
+        if (i4 < Q4) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dst[(4 * i4 + c) * LD + b] = xs[4 * j + c];  // zeros for patients past the batch
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < XPT; ++j) {
+        const int e = tid + 256 * j;
+        if (e < n_x) {
+          const int b = e / p.OBS, i = e - b * p.OBS;
+          dst[i * LD + b] = xs[j];
+        }
       }
     }
     // action columns (never masked): AD * nvalid values
@@ -153,6 +185,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
   __syncthreads();
 
   const f32x4* wbase = reinterpret_cast<const f32x4*>(p.wp) + (size_t)w * p.KQ4 * TPW * 64 + l;
+  // weight fragment registers live across steps: the first group of step s+1 is requested as soon as step s's MFMA loop
+  // ends, so its L2 round trip runs under the cell update, the x staging and the barrier
+  f32x4 wa[TPW], wb[TPW];
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) wa[tt] = wbase[(size_t)tt * 64];
 
   for (int s = 0; s < p.T; ++s) {
     const int t = p.reverse ? p.T - 1 - s : s;
@@ -203,11 +240,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
 #pragma unroll
       for (int tt = 0; tt < TPW; ++tt) wf[tt] = wbase[((size_t)q * TPW + tt) * 64];
     };
-    f32x4 wa[TPW], wb[TPW];
     const int n_full = p.Kq >> 2;        // groups with all 4 k-quads
     const int tail = p.Kq & 3;           // k-quads of the last, partial group (its fragments are zero padded)
     const int n_groups = n_full + (tail ? 1 : 0);
-    load_group(wa, 0);
     for (int q = 0; q < n_full; ++q) {
       load_group(wb, min(q + 1, n_groups - 1));  // clamped: the last prefetch may be a repeat, never out of bounds
       quads(wa, q, 0, 4);
@@ -215,6 +250,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
       for (int tt = 0; tt < TPW; ++tt) wa[tt] = wb[tt];
     }
     if (tail) quads(wa, n_full, 0, tail);
+    load_group(wa, 0);  // next step's first group (weights do not change within the launch)
 
     // cell update: lane (g, pc) holds gates i,f,g,o of unit u = (w*TPW + tt)*4 + g for patient 16c + pc
     float* tp = p.tape ? p.tape + (((size_t)t * gridDim.x + blockIdx.x) * 4 + w) * TPW * NT * 5 * 64 + l : nullptr;
