@@ -65,7 +65,7 @@ def _splitk_tn(lhs, rhs):
 
 
 class _LstmEncode(torch.autograd.Function):
-    """h_final = LSTM(window); backward = BPTT kernel + three BLAS GEMMs over K = T*B for the weight gradients."""
+    """h_final = LSTM(window); backward = BPTT kernel + one split-K BLAS GEMM over K = T*B for all weight and bias gradients."""
 
     @staticmethod
     def forward(ctx, x, a, mask, w_ih, w_hh, b_ih, b_hh, reverse):
@@ -101,7 +101,9 @@ class _LstmEncode(torch.autograd.Function):
         gh = grad_h.to(torch.float32).contiguous()
         dgates = torch.empty((T, B, 4 * H), device=xc.device, dtype=torch.float32)
         ad = 0 if ac is None else ac.shape[-1]
-        hprev = torch.empty((T, B, H + ad + 1), device=xc.device, dtype=torch.float32)
+        I = obs + ad
+        W = (I + H + 1 + 3) // 4 * 4
+        hprev = torch.empty((T, B, W), device=xc.device, dtype=torch.float32)  # [x*mask | a | h_prev | 1 | 0-pad]
         d = _desc(xc, ac, mc, wi, wh, bi, bh, reverse, True)
         h_dummy = torch.empty(1, device=xc.device)
         d.h_out, d.c_out = h_dummy.data_ptr(), h_dummy.data_ptr()  # unused by the backward, must be non-NULL
@@ -110,12 +112,14 @@ class _LstmEncode(torch.autograd.Function):
         with torch.cuda.device(xc.device):
             L.check(lib.hode_lstm_bwd(d, _stream()), "hode_lstm_bwd")
         dg2 = dgates.view(T * B, 4 * H)
-        xm = xc * mc if mc is not None else xc
-        g_wih_x = _splitk_tn(dg2, xm.view(T * B, obs))
-        g_ha = _splitk_tn(dg2, hprev.view(T * B, H + ad + 1))  # [grad_w_hh | action columns of grad_w_ih | grad_b]
-        g_whh = g_ha[:, :H].contiguous()
-        g_wih = g_wih_x if ad == 0 else torch.cat([g_wih_x, g_ha[:, H:H + ad]], dim=1)
-        g_b = g_ha[:, H + ad].contiguous()
+        if mc is not None:
+            torch.mul(xc, mc, out=hprev[:, :, :obs])   # the kernel leaves the first obs columns to the caller
+        else:
+            hprev[:, :, :obs].copy_(xc)
+        g = _splitk_tn(dg2, hprev.view(T * B, W))  # ONE product: [grad_w_ih | grad_w_hh | grad_b | 0]
+        g_wih = g[:, :I].contiguous()
+        g_whh = g[:, I:I + H].contiguous()
+        g_b = g[:, I + H].contiguous()
         return None, None, None, g_wih, g_whh, g_b, g_b.clone(), None
 
 

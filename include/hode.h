@@ -166,9 +166,10 @@ typedef struct hode_lstm_desc {
   /* backward */
   const float* grad_h_out; /* [B][H] cotangent of h_out */
   float* grad_gates;   /* out [T][B][4H]: d loss / d pre-activation gates per step (feeds the weight-gradient GEMMs) */
-  float* h_prev;       /* out [T][B][H + (I - obs_dim) + 1]: hidden state entering each step, the action columns of that
-                          step, and a constant 1 (the second GEMM operand: grad_gates^T h_prev gives grad_w_hh,
-                          grad_w_ih[:, obs:] and, from the ones column, grad_b_ih = grad_b_hh) */
+  float* h_prev;       /* out: the weight-gradient GEMM operand [T][B][W], W = roundup4(I + H + 1), per (t, b) row:
+                          obs_dim columns LEFT UNTOUCHED for the caller's x*mask | action columns (I - obs_dim) | hidden
+                          state entering the step (H) | 1 | 0...   grad_gates^T h_prev over K = T*B then is
+                          [grad_w_ih | grad_w_hh | grad_b_ih = grad_b_hh | 0] */
   void* workspace;     /* >= hode_lstm_workspace_bytes: packed weights (+ tape when save_tape) */
   size_t workspace_bytes;
 } hode_lstm_desc;
