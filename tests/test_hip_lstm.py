@@ -25,7 +25,7 @@ def _inputs(T, B, obs, seed, ad=1):
 
 
 @pytest.mark.parametrize("obs,H,B,T", [(80, 160, 100, 12), (40, 80, 77, 9), (80, 160, 1000, 5), (24, 44, 50, 7), (80, 160, 16, 3),
-                                       (80, 160, 33, 1)])
+                                       (80, 160, 33, 1), (37, 75, 53, 6), (10, 157, 40, 4)])  # last two: obs % 4 != 0, H % 4 != 0
 def test_final_state_matches_oracle(obs, H, B, T):
     from hode.lstm import lstm_final_state
     dev = _dev()
@@ -78,7 +78,8 @@ def test_forward_time_unmasked_variant():
     assert (h.cpu() - h_o[0]).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("obs,H,B,T", [(80, 160, 100, 8), (40, 80, 77, 6), (24, 44, 21, 5), (80, 160, 500, 3)])
+@pytest.mark.parametrize("obs,H,B,T", [(80, 160, 100, 8), (40, 80, 77, 6), (24, 44, 21, 5), (80, 160, 500, 3), (37, 75, 53, 4),
+                                       (10, 157, 40, 3)])  # last two: the scalar staging / store paths (obs, H not multiples of 4)
 def test_backward_matches_oracle_autograd(obs, H, B, T):
     """BPTT kernel + GEMMs vs autograd through the oracle's explicit-gate LSTM: rel-L2 <= 1e-4 on every parameter."""
     from hode.lstm import lstm_encode
