@@ -82,6 +82,14 @@ class CrpsDesc(C.Structure):
     ]
 
 
+class McKlDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_samples", C.c_int32), ("rows", C.c_int64), ("rate", C.c_float),
+        ("clamp_value", C.c_float),
+        ("mu", _fp), ("log_var", _fp), ("noise", _fp), ("kl", _fp), ("grad_mu", _fp), ("grad_log_var", _fp),
+    ]
+
+
 #: every symbol include/hode.h declares: (name, restype, argtypes)
 EXPORTS = (
     ("hode_version", C.c_int, ()),
@@ -96,6 +104,7 @@ EXPORTS = (
     ("hode_readout_workspace_bytes", C.c_size_t, (C.POINTER(ReadoutDesc),)),
     ("hode_readout_sse", C.c_int, (C.POINTER(ReadoutDesc), C.c_void_p)),
     ("hode_ensemble_crps", C.c_int, (C.POINTER(CrpsDesc), C.c_void_p)),
+    ("hode_mc_kl_exponential", C.c_int, (C.POINTER(McKlDesc), C.c_void_p)),
     ("hode_lstm_fwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
     ("hode_lstm_bwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
 )

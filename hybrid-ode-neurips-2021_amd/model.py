@@ -418,6 +418,7 @@ class VariationalInference:
         self.mc_size = mc_size
         self.elbo = elbo
         self.fuse_likelihood = True  # fused readout + masked-SSE kernel when the decoder supports the shape
+        self.fuse_mc_kl = True       # fused Monte-Carlo KL kernel for the Exponential prior
         self.model_name = "VI_{}_{}.pkl".format(encoder.model_name, decoder.model_name)
 
     def save(self, path, itr, best_loss):
@@ -470,6 +471,10 @@ class VariationalInference:
         tensor (sample axis first) instead of the reference's Python loop; same RNG stream order."""
         sigma = torch.exp(0.5 * log_var)
         eps = torch.randn((sample_size,) + tuple(sigma.shape), device=sigma.device, dtype=sigma.dtype)
+        if (mu.is_cuda and self.prior_log_pdf is ExponentialPrior.log_density
+                and type(self.encoder).log_density is GaussianReparam.log_density and self.fuse_mc_kl):
+            from hode import mckl  # one kernel, analytic gradients (hode_mc_kl_exponential)
+            return mckl.mc_kl_exponential(mu, log_var, eps, ExponentialPrior.rate, self.epsilon).sum(dim=-1)
         z = eps * sigma + mu
         z = torch.where(z <= 0.0, torch.full_like(z, self.epsilon), z)
         log_q = self.encoder.log_density(mu, log_var, z)

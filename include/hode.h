@@ -217,6 +217,23 @@ typedef struct hode_crps_desc {
   float* crps_sum;        /* out [T'][B]: sum over the obs components, or NULL */
 } hode_crps_desc;
 
+/* Monte-Carlo KL of the diagonal-Gaussian posterior against Exponential(rate) (reference model.py:1198-1214 with
+ * :18-31 and :41-45): kl[i] = mean_s ( log N(z_s; mu, sigma) - log Exp(z_s; rate) ) for element i = (patient, latent
+ * component), z_s = noise[s][i] * sigma + mu with non-positive draws replaced by clamp_value (no gradient through them). */
+typedef struct hode_mckl_desc {
+  uint32_t struct_size;
+  int32_t n_samples;     /* S */
+  int64_t rows;          /* B * D elements */
+  float rate;            /* 100 in the reference */
+  float clamp_value;     /* torch.finfo(float32).eps in the reference */
+  const float* mu;       /* [rows] */
+  const float* log_var;  /* [rows] */
+  const float* noise;    /* [S][rows] standard-normal draws */
+  float* kl;             /* out [rows] */
+  float* grad_mu;        /* out [rows] d kl[i] / d mu[i], or NULL */
+  float* grad_log_var;   /* out [rows] d kl[i] / d log_var[i], or NULL */
+} hode_mckl_desc;
+
 #define HODE_WS_RK_FWD 0
 #define HODE_WS_RK_BWD 1
 #define HODE_WS_DOPRI5_FWD 2
@@ -254,6 +271,8 @@ int hode_readout_sse(const hode_readout_desc* desc, void* hip_stream);
 
 /* CRPS = 1/M sum_m |x_m - y| - 1/M^2 sum_{i<j} |x_i - x_j| per scored element; one workgroup per (time, patient) */
 int hode_ensemble_crps(const hode_crps_desc* desc, void* hip_stream);
+
+int hode_mc_kl_exponential(const hode_mckl_desc* desc, void* hip_stream);
 
 int hode_lstm_fwd(const hode_lstm_desc* desc, void* hip_stream);
 int hode_lstm_bwd(const hode_lstm_desc* desc, void* hip_stream);
