@@ -59,26 +59,47 @@ struct RealArgs {
   float* __restrict__ grad_y0;
   float* __restrict__ tape;          // [inst][rows][B]
   float* __restrict__ partials;      // [n_waves][3]
+  float* __restrict__ dose_tab;      // [2][Ta + 1][B]: S_n and dS_n/dkel at the integer times n = 0..Ta (see real_dose)
   int B, T, Ta, H, perturb;
 };
 
 struct DoseK {
   float v, dk;
 };
-// Dose(t) and d Dose / d kel; terms with k > t vanish, so the sum stops at floor(t)
-HODE_DEV DoseK real_dose(const RealArgs& a, int p, float t, float kel) {
-  DoseK r{0.f, 0.f};
-  const int kmax = min(a.Ta, (int)__builtin_floorf(t));
-  for (int k = 1; k <= kmax; ++k) {
-    const float tau = (float)k;
-    if (t >= tau) {
-      const float d = tau - t;
-      const float e = a.act[(size_t)(k - 1) * a.B + p] * exp_f32(kel * d);
-      r.v += e;
-      r.dk = __builtin_fmaf(d, e, r.dk);
-    }
+// Dose(t) = sum_{k <= t} a[k-1] exp(kel (k - t)) and d Dose / d kel.  The reference re-sums all past doses at every rhs
+// call (model.py:653-657: an O(T B) reduction per call); evaluated like that here, the k-loop is a chain of dependent
+// global loads (35 us per rhs evaluation at T = 120, 5x everything else in the rhs).  With n = floor(t):
+//     Dose(t) = exp(kel (n - t)) S_n,   S_n = sum_{k <= n} a[k-1] exp(kel (k - n)) = a[n-1] + exp(-kel) S_{n-1}
+//     dS_n/dkel = exp(-kel) (dS_{n-1}/dkel - S_{n-1})
+// so every thread tabulates S_n and dS_n/dkel for its patient once per launch (real_dose_table, Ta steps) and an
+// evaluation is two loads and one exp.  Same function of (a, kel, t); the summation order differs from the reference's
+// (forward recurrence vs one flat sum), inside the test tolerance of the trajectory (tests/test_hip_real.py).
+HODE_DEV void real_dose_table(const RealArgs& a, int p, float kel) {
+  const size_t B = a.B;
+  float* S = a.dose_tab;
+  float* dS = a.dose_tab + (size_t)(a.Ta + 1) * B;
+  const float E = exp_f32(-kel);
+  float s = 0.f, ds = 0.f;
+  S[p] = 0.f;
+  dS[p] = 0.f;
+#pragma unroll 8
+  for (int n = 1; n <= a.Ta; ++n) {
+    const float an = a.act[(size_t)(n - 1) * B + p];
+    ds = E * (ds - s);
+    s = __builtin_fmaf(E, s, an);
+    S[(size_t)n * B + p] = s;
+    dS[(size_t)n * B + p] = ds;
   }
-  return r;
+}
+HODE_DEV DoseK real_dose(const RealArgs& a, int p, float t, float kel) {
+  const int n = min(a.Ta, (int)__builtin_floorf(t));
+  if (n < 1) return DoseK{0.f, 0.f};
+  const size_t B = a.B;
+  const float s = a.dose_tab[(size_t)n * B + p];
+  const float ds = a.dose_tab[(size_t)(a.Ta + 1 + n) * B + p];
+  const float dlt = (float)n - t;
+  const float e = exp_f32(kel * dlt);
+  return DoseK{e * s, e * __builtin_fmaf(dlt, s, ds)};
 }
 
 HODE_DEV float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -252,6 +273,7 @@ __global__ __launch_bounds__(64) void real_kernel(RealArgs a) {
   const size_t row = (size_t)a.B * D;
   const size_t B = a.B;
   const size_t tstride = (size_t)tl.rows() * B;
+  real_dose_table(a, p, kel);  // each thread reads back only its own column: no barrier needed
 
   if constexpr (!BWD) {
     float y[D];
@@ -409,15 +431,18 @@ int real_stages(int method) { return method == HODE_METHOD_EULER ? 1 : (method =
 int real_rows(const hode_solve_desc* d) { return 5 + 4 * d->hidden_dim + 5 * (d->latent_dim - 4); }
 
 struct RealLayout {
-  size_t tape, partials, total;
+  size_t tape, partials, dose, total;
 };
+// [ tape (bwd) | theta partials (bwd) | dose table (both) ]; the tape stays first: hode/real.py views it from offset 0
 RealLayout real_layout(const hode_solve_desc* d, bool bwd) {
-  RealLayout L{0, 0, 0};
-  if (!bwd) return L;
-  const size_t inst = (size_t)(d->n_times - 1) * real_stages(d->method);
+  RealLayout L{0, 0, 0, 0};
   size_t off = 0;
-  L.tape = off; off = ral256(off + inst * real_rows(d) * (size_t)d->batch * 4);
-  L.partials = off; off = ral256(off + (size_t)((d->batch + 63) / 64) * 3 * 4);
+  if (bwd) {
+    const size_t inst = (size_t)(d->n_times - 1) * real_stages(d->method);
+    L.tape = off; off = ral256(off + inst * real_rows(d) * (size_t)d->batch * 4);
+    L.partials = off; off = ral256(off + (size_t)((d->batch + 63) / 64) * 3 * 4);
+  }
+  L.dose = off; off = ral256(off + (size_t)2 * (d->n_action_times + 1) * (size_t)d->batch * 4);
   L.total = off;
   return L;
 }
@@ -434,7 +459,7 @@ int check_real(const hode_solve_desc* d, bool bwd) {
     return hode::fail(HODE_E_NULL, "t / y0 / dosage (dose table) / theta / w1 (flat weights) / h must be non-NULL");
   if (bwd && (!d->grad_h || !d->grad_y0 || !d->grad_theta)) return hode::fail(HODE_E_NULL, "grad_h / grad_y0 / grad_theta required");
   const RealLayout L = real_layout(d, bwd);
-  if (bwd && (!d->workspace || d->workspace_bytes < L.total))
+  if (!d->workspace || d->workspace_bytes < L.total)
     return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, L.total);
   return 0;
 }
@@ -465,6 +490,7 @@ int real_rk(const hode_solve_desc* d, bool bwd, hipStream_t s) {
   a.grad_h = d->grad_h; a.grad_y0 = d->grad_y0;
   a.tape = bwd ? (float*)(ws + L.tape) : nullptr;
   a.partials = bwd ? (float*)(ws + L.partials) : nullptr;
+  a.dose_tab = (float*)(ws + L.dose);
   a.B = d->batch; a.T = d->n_times; a.Ta = d->n_action_times; a.H = d->hidden_dim; a.perturb = d->perturb;
   int e;
   if (d->latent_dim == 4) e = bwd ? launch_real<4, true>(d, a, s) : launch_real<4, false>(d, a, s);

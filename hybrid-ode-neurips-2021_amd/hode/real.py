@@ -34,6 +34,9 @@ class _RealFixedGrid(torch.autograd.Function):
         assert wc.numel() == 9 * hidden + 2 + 3 * M * M, "flat weight buffer has the wrong length"
         h = torch.empty((tc.numel(), B, D), device=y0.device, dtype=torch.float32)
         d = _desc(y0c, tc, ac, thc, wc, h, method, perturb, hidden)
+        n = lib.hode_workspace_bytes(d, L.WS_RK_FWD)  # the per-patient dose table
+        ws = torch.empty(max(n, 4), device=y0.device, dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), n
         with torch.cuda.device(y0.device):
             L.check(lib.hode_rk_fwd(d, _stream()), "hode_rk_fwd[real]")
         ctx.save_for_backward(h, thc, wc, tc, ac)
@@ -73,11 +76,21 @@ class _RealFixedGrid(torch.autograd.Function):
         y3, a11, u11, u12, a21, u21, u22 = take(3), take(H), take(H), take(1), take(H), take(H), take(1)
         hh, rh, ur, uz, uh = (take(M) for _ in range(5)) if M > 0 else (None,) * 5
 
-        def outer(u, x):  # sum over instances and patients of u x^T
-            return torch.bmm(u, x.transpose(1, 2)).sum(0)
+        # sums over instances are (1 x inst) GEMMs: torch's strided sum over these shapes runs at a fraction of HBM speed
+        ones_i = torch.ones((1, inst), device=h.device, dtype=torch.float32)
+        ones_b = torch.ones((B, 1), device=h.device, dtype=torch.float32)
 
-        parts = [outer(u11, y3).reshape(-1), u11.sum(dim=(0, 2)), outer(u12, a11).reshape(-1), u12.sum(dim=(0, 2)),
-                 outer(u21, y3[:, :2]).reshape(-1), u21.sum(dim=(0, 2)), outer(u22, a21).reshape(-1), u22.sum(dim=(0, 2))]
+        def fold(part):  # (inst, m, n) -> (m, n)
+            return (ones_i @ part.reshape(inst, -1)).view(part.shape[1], part.shape[2])
+
+        def outer(u, x):  # sum over instances and patients of u x^T
+            return fold(torch.bmm(u, x.transpose(1, 2)))
+
+        def colsum(u):   # (inst, k, B) -> (k,)
+            return fold(u @ ones_b).reshape(-1)
+
+        parts = [outer(u11, y3).reshape(-1), colsum(u11), outer(u12, a11).reshape(-1), colsum(u12),
+                 outer(u21, y3[:, :2]).reshape(-1), colsum(u21), outer(u22, a21).reshape(-1), colsum(u22)]
         if M > 0:
             parts += [outer(uh, rh).reshape(-1), outer(uz, hh).reshape(-1), outer(ur, hh).reshape(-1)]
         return gy0, gth[:3].clone(), torch.cat(parts), None, None, None, None, None
