@@ -10,8 +10,23 @@
 //   * waves 1..3 integrate the learned latents of 16 patients each in the quad layout (a patient per DPP quad, each lane
 //     owns (D-4)/4 rows of tanh(W y + b) AND only the matching components of the state -- stage algebra on 1-2
 //     components instead of D), reading the expert stage states from LDS (one ds_read_b128, quad-broadcast).
-// One __syncthreads per step hands the ring over.  A workgroup = 4 waves = the 4 SIMDs of a CU; 209 workgroups at the
-// bench shape.  Each wave issues ~50 VALU instructions per rhs instead of ~117.
+// One __syncthreads per step hands the rings over.  A workgroup = 4 waves = the 4 SIMDs of a CU; 209 workgroups at the
+// bench shape.
+//
+// The kernels are bound by ISSUE SLOTS (every wave-instruction ~2.4 ns), so the instruction streams are
+// written for count, not for flops:
+//   * packed fp32 (f2 = ext_vector_type(2), v_pk_fma_f32) by hand: the learned block as (row0, row1) accumulators with the
+//     state component broadcast through op_sel, two interleaved chains per product (a packed result cannot feed the very
+//     next instruction), tanh's scale folded into the weights; the expert wave's stage / cotangent algebra on the pairs
+//     (Disease, ImmuneReact), (Immunity, Dose2);
+//   * the dose schedule is evaluated by the learned waves, stage q by quad lane q, and handed to the expert wave through a
+//     third LDS ring (4 stages in parallel instead of 4 x 9 serial instructions);
+//   * HODE_FLAG_TAPE: the forward leaves the expert block's intermediate stage states in the workspace, the backward's
+//     expert wave loads them an iteration ahead instead of re-integrating (bit-identical, +16 B x 3 per patient / step);
+//   * the time grid sits in LDS (dynamic shared memory, hence n_times <= 8192 for this layout);
+//   * time loops unrolled by two through a generic lambda so that ring parities are immediates; all ring reads of a step
+//     are issued up front and pinned with sched_barrier; per-step stores are unpredicated (lanes beyond the batch hold
+//     bit-identical copies of patient B-1); the backward epilogue reduces with DPP row rotations + one LDS join.
 #include <hip/hip_runtime.h>
 
 #include "../../include/hode.h"
@@ -355,8 +370,10 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
 // latents, so no expert term enters d/dy_learned), while the expert cotangent needs c_s = sum_j W[j][0..3] u_j from
 // the learned block at every stage.  Per iteration k (ML handles step m_k = T-2-k):
 //   wave 0 (expert):  (b) adjoint of step m_{k-1}: reads its own stage states / doses and the learned block's c_s from
-//                     the rings of iteration k-1;  (a) recomputes the stage states of step m_{k+1} into the rings
-//   waves 1..3 (ML):  recompute + adjoint of step m_k (stage states from the ring), publish c_s
+//                     the rings of iteration k-1;  (a) publishes the stage states of step m_{k+1} into the rings
+//                     (re-integrated from h, or -- TAPE -- loaded from the forward's tape one iteration earlier)
+//   waves 1..3 (ML):  recompute + adjoint of step m_k (stage states from the ring), publish c_s; with the tape also the
+//                     step's doses (v, d/dkel), stage q by quad lane q
 //   one __syncthreads.  Rings are double buffered by iteration parity; (b) runs before (a) because (a) overwrites the
 //   buffer (b) reads.
 struct SplitBwdArgs {
