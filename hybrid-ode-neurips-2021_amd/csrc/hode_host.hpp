@@ -50,6 +50,8 @@ int dp_dispatch_d12(const DpLaunch&, const DpArgs&, hipStream_t);
 // neural rhs (hode_neural.hip)
 size_t neural_workspace_bytes(const hode_solve_desc* d, bool bwd);
 int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
+struct NeuralArgs;
+int launch_neural_mf(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s);  // hode_neural_mf.hip
 
 // real-data rhs (hode_real.hip)
 size_t real_workspace_bytes(const hode_solve_desc* d, bool bwd);

@@ -13,31 +13,14 @@
 // Dose(t) = dosage * #{k : tau_k == t} is an impulse that only exists when a stage time hits a dose time exactly
 // (reference model.py:1017), so stage times are formed with non-contracted fp32 ops like the reference's tensors.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/hode.h"
 #include "hode_common.hpp"
 #include "hode_host.hpp"
+#include "hode_neural_args.hpp"
 
 namespace hode {
-
-struct NeuralArgs {
-  const float* __restrict__ t;
-  const float* __restrict__ y0;
-  const float* __restrict__ dosage;
-  const float* __restrict__ dose_times;
-  const float* __restrict__ w1;   // [HD][D+1]
-  const float* __restrict__ b1;   // [HD]
-  const float* __restrict__ w2t;  // [HD][D]   (W2 transposed once per call: column n of W2 is contiguous)
-  const float* __restrict__ b2;   // [D]
-  float* __restrict__ h;
-  const float* __restrict__ grad_h;
-  float* __restrict__ grad_y0;
-  float* __restrict__ a1t;   // tapes (backward)
-  float* __restrict__ u1t;
-  float* __restrict__ yet;
-  float* __restrict__ u2t;
-  int B, T, K, perturb;
-};
 
 __global__ void transpose_w2_kernel(const float* __restrict__ w2, float* __restrict__ w2t, int D, int HD) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,33 +28,6 @@ __global__ void transpose_w2_kernel(const float* __restrict__ w2, float* __restr
     const int c = i / HD, n = i - c * HD;
     w2t[n * D + c] = w2[i];
   }
-}
-
-constexpr float kThird = (float)(1.0 / 3.0);
-constexpr float kTwoThird = (float)(2.0 / 3.0);
-
-struct NStageTimes {
-  float t0, t1, dt, ta, tb, t_first, t_last;
-  HODE_DEV NStageTimes(const float* __restrict__ t, int n, int perturb, int method) {
-    t0 = t[n];
-    t1 = t[n + 1];
-    dt = t1 - t0;
-    t_first = perturb ? nextafter_up(t0) : t0;
-    t_last = perturb ? nextafter_down(t1) : t1;
-    if (method == HODE_METHOD_RK4_38) {
-      ta = add_rn(t0, mul_rn(dt, kThird));
-      tb = add_rn(t0, mul_rn(dt, kTwoThird));
-    } else {
-      ta = add_rn(t0, mul_rn(0.5f, dt));
-      tb = ta;
-    }
-  }
-};
-
-HODE_DEV float neural_dose(const NeuralArgs& a, int p, float dosage, float t) {
-  float cnt = 0.f;
-  for (int k = 0; k < a.K; ++k) cnt += (a.dose_times[(size_t)p * a.K + k] == t) ? 1.0f : 0.0f;
-  return dosage * cnt;
 }
 
 // k = f(ye), ye = [y, dose].  If A1 != nullptr the hidden activations are written to A1[n * strideB] (tape).
@@ -379,6 +335,12 @@ int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s) {
   a.h = d->h; a.grad_h = d->grad_h; a.grad_y0 = d->grad_y0;
   a.a1t = (float*)(ws + L.a1t); a.u1t = (float*)(ws + L.u1t); a.yet = (float*)(ws + L.yet); a.u2t = (float*)(ws + L.u2t);
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
+  a.w2 = d->w2;
+  {
+    // default: the matrix-core kernels (hode_neural_mf.hip); HODE_NEURAL_LAYOUT=t selects the one-patient-per-lane ones
+    const char* env = getenv("HODE_NEURAL_LAYOUT");
+    if (!(env && env[0] == 't')) return launch_neural_mf(d, a, bwd, s);
+  }
   const int D = d->latent_dim, HD = 10 * D;
   hipLaunchKernelGGL(hode::transpose_w2_kernel, dim3((D * HD + 255) / 256), dim3(256), 0, s, d->w2, (float*)(ws + L.w2t), D, HD);
   if (int e = hode::hip_fail(hipGetLastError(), "transpose_w2 launch")) return e;

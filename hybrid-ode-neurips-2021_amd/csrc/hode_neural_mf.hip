@@ -1,0 +1,307 @@
+// NeuralODE rhs on the matrix cores: dy/dt = tanh(W2 tanh(W1 [y, Dose(t)] + b1) + b2) (reference model.py:969-1026) inside
+// the fixed-grid euler / midpoint / rk4(3/8) loop and its discrete adjoint, gfx950.  Same C-ABI contract, tape format and
+// arithmetic (up to summation order) as the one-patient-per-lane kernels in hode_neural.hip, which stay as the fallback
+// (HODE_NEURAL_LAYOUT=t).
+//
+// A wave owns 16 patients for the whole time loop; the state never leaves registers.  With v_mfma_f32_16x16x4_f32
+// (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15], C/D rows 4 (lane >> 4) + reg, column lane & 15) and
+// g = lane >> 4, n = lane & 15 (the patient):
+//   * a vector over at most 16 "rows" (the input e = [y, Dose, 0..], an output, a cotangent) is ONE accumulator tile:
+//     lane (g, n) holds rows 4g + r in register r;
+//   * the contraction index of every product is ordered so that k-chunk r consists of the rows {4g + r : g = 0..3}: then
+//     the B fragment of chunk r IS register r of the tile the previous product (or the element-wise step) left -- no
+//     cross-lane traffic, no LDS, anywhere in the loop;
+//   * the four weight operands (W1, W2, W2^T, W1^T, zero padded to 16-row tiles) are gathered once per launch into
+//     that fragment order and stay in registers: 4 x 4 x HT floats per lane, HT = ceil(10 D / 16) hidden tiles.
+// Per rhs evaluation: 4 HT MFMAs for the hidden layer, 4 HT for the output layer (4 partial accumulators: a single
+// dependent chain would serialise on the MFMA latency), tanh on 4 HT + 4 values per lane; the VJP costs the same again.
+// The weight gradients are outer products summed over patients: as in hode_neural.hip the backward tapes their operands
+// patient-minor for the caller's BLAS GEMMs (hode/neural.py) -- same offsets, same layout.
+#include <hip/hip_runtime.h>
+
+#include "../../include/hode.h"
+#include "hode_common.hpp"
+#include "hode_host.hpp"
+#include "hode_neural_args.hpp"
+
+namespace hode {
+
+typedef float v4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+struct NeuralMf {
+  static constexpr int HD = 10 * D;
+  static constexpr int HT = (HD + 15) / 16;   // hidden tiles
+  static constexpr int GD = D / 4, RD = D % 4;  // tile position of the Dose input (row D)
+  float A1[HT][4], A2[HT][4], A3[HT][4], A4[HT][4];
+  v4 bias1[HT];
+  v4 bias2;
+  int g, n;
+
+  HODE_DEV void load(const NeuralArgs& a, int lane) {
+    g = lane >> 4;
+    n = lane & 15;
+    const int m = lane & 15;
+    const float* W1 = a.w1;   // [HD][D + 1]
+    const float* W2 = a.w2;   // [D][HD]
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 4 * g + r;          // k index of this lane within chunk r
+        const int hrow = 16 * i + m;        // A-row of hidden-sized products
+        const int hcol = 16 * i + 4 * g + r;  // k index over the hidden axis
+        A1[i][r] = (hrow < HD && col <= D) ? W1[(size_t)hrow * (D + 1) + col] : 0.f;        // W1[16i+m][4g+r]
+        A2[i][r] = (m < D && hcol < HD) ? W2[(size_t)m * HD + hcol] : 0.f;                  // W2[m][16i+4g+r]
+        A3[i][r] = (hrow < HD && col < D) ? W2[(size_t)col * HD + hrow] : 0.f;              // W2^T[16i+m][4g+r]
+        A4[i][r] = (hcol < HD && m <= D) ? W1[(size_t)hcol * (D + 1) + m] : 0.f;            // W1^T[m][16i+4g+r]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + 4 * g + r;
+        bias1[i][r] = row < HD ? a.b1[row] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias2[r] = (4 * g + r) < D ? a.b2[4 * g + r] : 0.f;
+  }
+
+  // hidden activations a1 (tile i, register r <-> hidden unit 16i + 4g + r) and k = f(e) for the input tile e
+  HODE_DEV v4 rhs(const v4& e, v4 (&a1)[HT]) const {
+    v4 acc[HT];
+#pragma unroll
+    for (int i = 0; i < HT; ++i) acc[i] = bias1[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < HT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[i][r], e[r], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < HT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1[i][r] = tanh_f32(acc[i][r]);
+    v4 z[4];
+    z[0] = bias2;
+    z[1] = z[2] = z[3] = v4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < HT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i][r], a1[i][r], z[r], 0, 0, 0);
+    const v4 zs = (z[0] + z[1]) + (z[2] + z[3]);
+    v4 k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) k[r] = tanh_f32(zs[r]);
+    return k;
+  }
+
+  // VJP at a stage with activations a1 and output k: returns (df/de)^T gk; u2, u1 are the pre-activation cotangents
+  HODE_DEV v4 vjp(const v4 (&a1)[HT], const v4& k, const v4& gk, v4& u2, v4 (&u1)[HT]) const {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u2[r] = gk[r] * __builtin_fmaf(-k[r], k[r], 1.0f);
+    v4 acc[HT];
+#pragma unroll
+    for (int i = 0; i < HT; ++i) acc[i] = v4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < HT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[i][r], u2[r], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < HT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u1[i][r] = acc[i][r] * __builtin_fmaf(-a1[i][r], a1[i][r], 1.0f);
+    v4 z[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = v4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < HT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[i][r], u1[i][r], z[r], 0, 0, 0);
+    return (z[0] + z[1]) + (z[2] + z[3]);
+  }
+};
+
+// the state tile of patient p: rows < D from memory, everything else 0
+template <int D>
+HODE_DEV v4 mf_load_rows(const float* __restrict__ src, int g) {
+  v4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (4 * g + r) < D ? src[4 * g + r] : 0.f;
+  return v;
+}
+template <int D>
+HODE_DEV void mf_store_rows(float* __restrict__ dst, int g, const v4& v, bool live) {
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if ((4 * g + r) < D) dst[4 * g + r] = v[r];
+}
+template <int D>
+HODE_DEV v4 mf_with_dose(const v4& y, float dose, int g) {  // e = [y, Dose, 0...]: row D lives in tile position (GD, RD)
+  v4 e = y;
+  if (g == NeuralMf<D>::GD) e[NeuralMf<D>::RD] = dose;
+  return e;
+}
+
+template <int D, int METHOD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void neural_mf_fwd_kernel(NeuralArgs a) {
+  const int lane = threadIdx.x;
+  NeuralMf<D> nn;
+  nn.load(a, lane);
+  const int g = nn.g;
+  const int pr = blockIdx.x * 16 + nn.n;
+  const bool live = pr < a.B;
+  const int p = live ? pr : a.B - 1;
+  const float dosage = a.dosage[p];
+  const size_t row = (size_t)a.B * D;
+  v4 y = mf_load_rows<D>(a.y0 + (size_t)p * D, g);
+  float* hp = a.h + (size_t)p * D;
+  mf_store_rows<D>(hp, g, y, live);
+  v4 a1[NeuralMf<D>::HT];
+  for (int nstep = 0; nstep + 1 < a.T; ++nstep) {
+    const NStageTimes st(a.t, nstep, a.perturb, METHOD);
+    const float dt = st.dt;
+    const v4 k1 = nn.rhs(mf_with_dose<D>(y, neural_dose(a, p, dosage, st.t_first), g), a1);
+    if constexpr (METHOD == HODE_METHOD_EULER) {
+      y = y + dt * k1;
+    } else if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
+      const v4 Y = y + (0.5f * dt) * k1;
+      const v4 k2 = nn.rhs(mf_with_dose<D>(Y, neural_dose(a, p, dosage, st.ta), g), a1);
+      y = y + dt * k2;
+    } else {
+      v4 Y = y + (dt * k1) * kThird;
+      const v4 k2 = nn.rhs(mf_with_dose<D>(Y, neural_dose(a, p, dosage, st.ta), g), a1);
+      Y = y + dt * (k2 - k1 * kThird);
+      const v4 k3 = nn.rhs(mf_with_dose<D>(Y, neural_dose(a, p, dosage, st.tb), g), a1);
+      Y = y + dt * ((k1 - k2) + k3);
+      const v4 k4 = nn.rhs(mf_with_dose<D>(Y, neural_dose(a, p, dosage, st.t_last), g), a1);
+      y = y + ((k1 + 3.0f * (k2 + k3)) + k4) * (dt * 0.125f);
+    }
+    hp += row;
+    mf_store_rows<D>(hp, g, y, live);
+  }
+}
+
+template <int D, int METHOD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void neural_mf_bwd_kernel(NeuralArgs a) {
+  constexpr int HD = 10 * D;
+  constexpr int HT = NeuralMf<D>::HT;
+  constexpr int NS = METHOD == HODE_METHOD_EULER ? 1 : (METHOD == HODE_METHOD_MIDPOINT ? 2 : 4);
+  const int lane = threadIdx.x;
+  NeuralMf<D> nn;
+  nn.load(a, lane);
+  const int g = nn.g;
+  const int pr = blockIdx.x * 16 + nn.n;
+  const bool live = pr < a.B;
+  const int p = live ? pr : a.B - 1;
+  const float lv = live ? 1.0f : 0.0f;
+  const size_t B = a.B;
+  const float dosage = a.dosage[p];
+  const size_t row = B * D;
+  v4 lam = lv * mf_load_rows<D>(a.grad_h + (size_t)(a.T - 1) * row + (size_t)p * D, g);
+
+  // tapes: operand rows patient-minor, [inst][rows][B]
+  auto tape_hidden = [&](float* base, size_t inst, const v4 (&v)[HT]) {
+    if (!live) return;
+    float* dst = base + inst * HD * B + p;
+#pragma unroll
+    for (int i = 0; i < HT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rw = 16 * i + 4 * g + r;
+        if (rw < HD) dst[(size_t)rw * B] = v[i][r];
+      }
+  };
+  auto tape_rows = [&](float* base, size_t inst, int nrows, const v4& v) {
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rw = 4 * g + r;
+      if (rw < nrows) base[(inst * nrows + rw) * B + p] = v[r];
+    }
+  };
+
+  for (int nstep = a.T - 2; nstep >= 0; --nstep) {
+    const NStageTimes st(a.t, nstep, a.perturb, METHOD);
+    const float dt = st.dt;
+    const size_t i0 = (size_t)nstep * NS;
+    const v4 y = mf_load_rows<D>(a.h + (size_t)nstep * row + (size_t)p * D, g);
+    v4 e[NS], k[NS], a1[NS][HT];
+    // ---- recompute the stages (inputs and hidden activations go to the tape as they are formed)
+    e[0] = mf_with_dose<D>(y, neural_dose(a, p, dosage, st.t_first), g);
+    k[0] = nn.rhs(e[0], a1[0]);
+    if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
+      e[1] = mf_with_dose<D>(y + (0.5f * dt) * k[0], neural_dose(a, p, dosage, st.ta), g);
+      k[1] = nn.rhs(e[1], a1[1]);
+    } else if constexpr (METHOD == HODE_METHOD_RK4_38) {
+      e[1] = mf_with_dose<D>(y + (dt * k[0]) * kThird, neural_dose(a, p, dosage, st.ta), g);
+      k[1] = nn.rhs(e[1], a1[1]);
+      e[2] = mf_with_dose<D>(y + dt * (k[1] - k[0] * kThird), neural_dose(a, p, dosage, st.tb), g);
+      k[2] = nn.rhs(e[2], a1[2]);
+      e[3] = mf_with_dose<D>(y + dt * ((k[0] - k[1]) + k[2]), neural_dose(a, p, dosage, st.t_last), g);
+      k[3] = nn.rhs(e[3], a1[3]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      tape_rows(a.yet, i0 + s, D + 1, e[s]);
+      tape_hidden(a.a1t, i0 + s, a1[s]);
+    }
+    // ---- adjoint of the stages
+    auto vjp = [&](int s, const v4& gk) {
+      v4 u2, u1[HT];
+      v4 av = nn.vjp(a1[s], k[s], gk, u2, u1);
+      tape_rows(a.u2t, i0 + s, D, u2);
+      tape_hidden(a.u1t, i0 + s, u1);
+      if (g == NeuralMf<D>::GD) av[NeuralMf<D>::RD] = 0.f;  // the Dose input is not a state
+      return av;
+    };
+    if constexpr (METHOD == HODE_METHOD_EULER) {
+      lam = lam + vjp(0, dt * lam);
+    } else if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
+      const v4 a1v = vjp(1, dt * lam);
+      lam = lam + a1v;
+      lam = lam + vjp(0, (0.5f * dt) * a1v);
+    } else {
+      const float w1 = dt * 0.125f, w3 = dt * 0.375f;
+      const v4 a3 = vjp(3, w1 * lam);
+      v4 da = dt * a3;
+      v4 g1 = w1 * lam + da;
+      v4 g2 = w3 * lam - da;
+      const v4 gg = w3 * lam + da;
+      lam = lam + a3;
+      const v4 a2 = vjp(2, gg);
+      da = dt * a2;
+      g2 = g2 + da;
+      g1 = g1 - kThird * da;
+      lam = lam + a2;
+      const v4 a1v = vjp(1, g2);
+      g1 = g1 + kThird * (dt * a1v);
+      lam = lam + a1v;
+      lam = lam + vjp(0, g1);
+    }
+    lam = lam + lv * mf_load_rows<D>(a.grad_h + (size_t)nstep * row + (size_t)p * D, g);
+  }
+  mf_store_rows<D>(a.grad_y0 + (size_t)p * D, g, lam, live);
+}
+
+template <int D>
+int launch_neural_mf_d(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s) {
+  const dim3 grid((d->batch + 15) / 16), block(64);
+#define HODE_NEURAL_MF_LAUNCH(M)                                                                   \
+  if (bwd) hipLaunchKernelGGL((neural_mf_bwd_kernel<D, M>), grid, block, 0, s, a);                 \
+  else hipLaunchKernelGGL((neural_mf_fwd_kernel<D, M>), grid, block, 0, s, a);
+  switch (d->method) {
+    case HODE_METHOD_EULER: HODE_NEURAL_MF_LAUNCH(HODE_METHOD_EULER) break;
+    case HODE_METHOD_MIDPOINT: HODE_NEURAL_MF_LAUNCH(HODE_METHOD_MIDPOINT) break;
+    default: HODE_NEURAL_MF_LAUNCH(HODE_METHOD_RK4_38) break;
+  }
+  return hip_fail(hipGetLastError(), "neural MFMA kernel launch");
+}
+
+int launch_neural_mf(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s) {
+  switch (d->latent_dim) {
+    case 6: return launch_neural_mf_d<6>(d, a, bwd, s);
+    case 8: return launch_neural_mf_d<8>(d, a, bwd, s);
+    default: return launch_neural_mf_d<12>(d, a, bwd, s);
+  }
+}
+
+}  // namespace hode
