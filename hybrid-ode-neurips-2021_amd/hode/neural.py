@@ -72,10 +72,18 @@ class _NeuralFixedGrid(torch.autograd.Function):
             z = torch.zeros_like
             return gy0, z(w1c), z(b1c), z(w2c), z(b2c), None, None, None, None, None
         a1t, u1t, yet, u2t = tape(0, HD), tape(1, HD), tape(2, D + 1), tape(3, D)
-        gw1 = torch.bmm(u1t, yet.transpose(1, 2)).sum(0)
-        gw2 = torch.bmm(u2t, a1t.transpose(1, 2)).sum(0)
-        gb1 = u1t.sum(dim=(0, 2))
-        gb2 = u2t.sum(dim=(0, 2))
+        # sums over the instance axis as (1 x inst) GEMMs, over patients as GEMVs with a ones vector: torch's strided
+        # reductions over these shapes run at a fraction of the HBM rate
+        ones_i = torch.ones((1, inst), device=h.device, dtype=torch.float32)
+        ones_b = torch.ones((B, 1), device=h.device, dtype=torch.float32)
+
+        def fold(part):  # (inst, m, n) -> (m, n)
+            return (ones_i @ part.reshape(inst, -1)).view(part.shape[1], part.shape[2])
+
+        gw1 = fold(torch.bmm(u1t, yet.transpose(1, 2)))
+        gw2 = fold(torch.bmm(u2t, a1t.transpose(1, 2)))
+        gb1 = fold(u1t @ ones_b).reshape(-1)
+        gb2 = fold(u2t @ ones_b).reshape(-1)
         return gy0, gw1, gb1, gw2, gb2, None, None, None, None, None
 
 

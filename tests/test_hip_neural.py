@@ -20,12 +20,19 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+@pytest.mark.parametrize("layout", ["matrix-cores", "lane-per-patient"])
 @pytest.mark.parametrize("D", [6, 8, 12])
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
-def test_neural_forward_backward_vs_oracle(D, method):
+def test_neural_forward_backward_vs_oracle(D, method, layout, monkeypatch):
+    """Both kernel families behind HODE_RHS_NEURAL: hode_neural_mf.hip (default) and hode_neural.hip (HODE_NEURAL_LAYOUT=t);
+    N = 70 leaves the last 16-patient wave of the matrix-core layout partly empty."""
     from hode import synth
     from hode.neural import neural_solve
     dev = _dev()
+    if layout == "lane-per-patient":
+        monkeypatch.setenv("HODE_NEURAL_LAYOUT", "t")
+    else:
+        monkeypatch.delenv("HODE_NEURAL_LAYOUT", raising=False)
     N, T = 70, 14
     inp = synth.solver_inputs(N, T, D, seed=D)
     inp["z0"] = inp["z0"] * 30.0
