@@ -56,6 +56,9 @@ int launch_neural_mf(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hi
 // real-data rhs (hode_real.hip)
 size_t real_workspace_bytes(const hode_solve_desc* d, bool bwd);
 int real_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
+struct RealArgs;
+bool real_mf_supported(const hode_solve_desc* d);                                              // hode_real_mf.hip
+int launch_real_mf(const hode_solve_desc* d, const RealArgs& a, bool bwd, hipStream_t s);
 
 // MFMA-layout Roche kernels (hode_rk_mf.hip)
 bool mf_supported(const hode_solve_desc* d);
