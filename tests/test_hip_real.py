@@ -28,11 +28,18 @@ def _flat(f):
     return ps
 
 
-@pytest.mark.parametrize("D,H", [(20, 43), (4, 9)])
+@pytest.mark.parametrize("layout", ["matrix-cores", "lane-per-patient"])
+@pytest.mark.parametrize("D,H", [(20, 43), (4, 9), (20, 17), (20, 64)])
 @pytest.mark.parametrize("method,perturb", [("midpoint", True), ("rk4", True), ("euler", False)])
-def test_real_forward_backward_vs_oracle(D, H, method, perturb):
+def test_real_forward_backward_vs_oracle(D, H, method, perturb, layout, monkeypatch):
+    """Both kernel families behind HODE_RHS_ROCHE_REAL: hode_real_mf.hip (default at D = 20; hidden 17 / 43 / 64 exercise
+    2, 3 and 4 hidden tiles) and hode_real.hip (HODE_REAL_LAYOUT=t; always for D = 4)."""
     from hode.real import real_solve
     dev = _dev()
+    if layout == "lane-per-patient":
+        monkeypatch.setenv("HODE_REAL_LAYOUT", "t")
+    else:
+        monkeypatch.delenv("HODE_REAL_LAYOUT", raising=False)
     B, Ta, t0 = 37, 30, 8
     gen = torch.Generator().manual_seed(D + H)
     torch.manual_seed(D)
