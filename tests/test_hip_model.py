@@ -99,3 +99,39 @@ def test_state_dict_roundtrip_and_training_step_changes_only_optimised_params(tm
     assert set(ck) == {"itr", "encoder_state_dict", "decoder_state_dict", "best_loss"}
     dec.load_state_dict(ck["decoder_state_dict"])
     assert torch.isfinite(l0)
+
+
+@pytest.mark.parametrize("noise_level", [0.2, 0.4, 0.6, 0.8, 1.0])
+@pytest.mark.parametrize("method_name,D,roche", [("hybrid", 12, True), ("expert", 4, True), ("neural", 12, False)])
+def test_noise_level_sweep_loss_and_adjoint_grads(noise_level, method_name, D, roche):
+    """BASELINE config 4: the noise-level sweep (`experiments/run_noise_level.sh`, `generated_data/generate_data_noise.py`:
+    measurements += randn * (level - 0.2), seed 666) through loss + discrete-adjoint backward for the three model
+    families the sweep trains (`--method` neural / expert / hybrid), rk4, against the CPU oracle."""
+    from hode import synth
+    dev = _dev()
+    obs, T, B, step = 80, 24, 40, synth.STEP
+    torch.manual_seed(2)
+    enc = model.EncoderLSTM(obs + 1, obs * 2, D, device=dev)
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * step, step, roche=roche, method="rk4", device=dev)
+    vi = model.VariationalInference(enc, dec, elbo=False)
+    enc_o = EncoderLSTMOracle(obs + 1, obs * 2, D)
+    dec_o = ovi.DecoderOracle(obs, D, (T - 1) * step, step, roche=roche, method="rk4")
+    enc_o.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+    dec_o.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    sol = synth.solver_inputs(B, T, D, seed=5)
+    ob = synth.observation_inputs(B, T, obs, seed=5)
+    torch.manual_seed(666)
+    x = ob["measurements"] + torch.randn_like(ob["measurements"]) * (noise_level - 0.2)
+    data = {"measurements": x, "actions": sol["actions"], "masks": ob["masks"]}
+    loss = vi.loss({k: v.to(dev) for k, v in data.items()})
+    loss.backward()
+    loss_o = ovi.vi_loss(enc_o, dec_o, data, elbo=False)
+    loss_o.backward()
+    assert abs(loss.item() - loss_o.item()) <= 2e-4 * abs(loss_o.item())
+    assert (vi.h_hat.detach().cpu() - odeint_h(dec_o, enc_o, data)).abs().max().item() <= 3e-4
+    for (n, p), (_, po) in zip(list(enc.named_parameters()) + list(dec.named_parameters()),
+                               list(enc_o.named_parameters()) + list(dec_o.named_parameters())):
+        if po.grad is None or float(po.grad.abs().max()) < 1e-12:
+            continue
+        assert p.grad is not None, n
+        assert _rel(p.grad, po.grad) <= 2e-3, (n, noise_level, _rel(p.grad, po.grad))
