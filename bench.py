@@ -157,6 +157,48 @@ def full_step_ms(dev, iters=5):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
+def dopri5_step(dev, rank, dist=None, iters=3):
+    """Extra (not the headline; BASELINE config 3 per GPU): the same patients through the adaptive Dormand-Prince solve
+    (rtol 1e-7, atol 1e-8, per-rank batch-global controller) + its tape adjoint, and -- when distributed -- the all-reduce
+    of the parameter gradients.  Max over ranks, like the headline."""
+    from hode import synth, adaptive
+    inp = synth.solver_inputs(N_PER_GPU, T, D, seed=synth.SEED + rank)
+    w, b = synth.default_ml_weights(D)
+    theta = torch.tensor((2.0, 2.0) + (1.0,) * 11 + (0.0,) * 3, device=dev)
+    chan = inp["actions"][..., 0]
+    dosage = chan.max(dim=0)[0].to(dev)
+    times = (torch.nonzero((chan != 0).t())[:, 1].reshape(N_PER_GPU, -1) * synth.STEP).float().to(dev)
+    y0 = inp["z0"].to(dev).requires_grad_(True)
+    wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    t = inp["t"].to(dev)
+    cot = torch.randn(T, N_PER_GPU, D, device=dev)
+
+    def step():
+        y0.grad = wg.grad = bg.grad = None
+        h = adaptive.roche_dopri5(y0, theta, wg, bg, t, dosage, times, rtol=1e-7, atol=1e-8)
+        (h * cot).sum().backward()
+        if dist is not None:
+            flat = torch.cat([wg.grad.flatten(), bg.grad.flatten()])
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+
+    step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    if dist is not None:
+        tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+    return ms, dict(adaptive.last_stats)
+
+
 def kernel_times(plan, iters=20):
     """Average duration of the forward kernel and of the adjoint kernel ALONE (no memset, no partial fold -- the quantity
     rocprofv3's kernel stats report), plus the whole backward call, from HIP events on the launch stream."""
@@ -189,6 +231,7 @@ def main():
     ap.add_argument("--sync-allreduce", action="store_true", help="N>1: wait for each step's gradient all-reduce before the next solve")
     ap.add_argument("--no-tape", action="store_true", help="backward re-integrates the expert stages instead of reading the forward's tape")
     ap.add_argument("--full-step", action="store_true", help="also time one full training step (encoder + loss) as an extra field")
+    ap.add_argument("--dopri5", action="store_true", help="also time the adaptive (dopri5) solve + adjoint at the same shape (BASELINE config 3 per GPU) as an extra field")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -277,6 +320,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    dp = dopri5_step(dev, rank, dist) if args.dopri5 else None  # every rank takes part (its all-reduce is collective)
     out = None
     if rank == 0:
         fwd_s, bwd_s, bwd_call_s = kernel_times(plan)
@@ -325,6 +369,11 @@ def main():
             ms_full = full_step_ms(dev)
             out["full_training_step"] = {"ms": ms_full, "trajectories_per_s": N_PER_GPU / ms_full * 1e3,
                                          "what": "EncoderLSTM(81->160, MFMA) + rk4 solve + readout + masked SSE + MC-KL, fwd+bwd"}
+        if dp is not None:
+            out["dopri5_step"] = {"ms": dp[0], "trajectories_per_s": N_PER_GPU * world / dp[0] * 1e3, "rtol": 1e-7, "atol": 1e-8,
+                                  "n_accepted": dp[1]["n_accepted"], "n_rejected": dp[1]["n_rejected"],
+                                  "what": "dopri5 solve (one launch per attempted step, batch-global controller per rank) + "
+                                          "tape adjoint" + ("" if dist is None else " + rccl all-reduce of the parameter grads")}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(inp, wb)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
