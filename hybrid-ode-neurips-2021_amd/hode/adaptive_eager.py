@@ -1,0 +1,204 @@
+"""Dormand-Prince 5(4) for right-hand sides that have no fused adaptive kernel (NeuralODE).
+
+``torchdiffeq.odeint(func, y0, t, rtol=, atol=, method="dopri5")`` semantics (the reference's default solver,
+sim_config.py:50, reached with the neural rhs by ``run_simulation --method=neural``; call site model.py:1116) on the
+tensors' own device: the rhs is the module's torch ``forward(t, y)``, i.e. GPU element-wise / GEMM launches per stage --
+the way the reference itself runs -- NOT a hand-written kernel.  The fused adaptive kernels (``hode.adaptive``,
+``csrc/hode_dopri5*``) cover the Roche rhs; this module exists so that the remaining (rhs, "dopri5") combinations of the
+reference's call surface integrate instead of raising.  Callers announce it once with a warning (model.py).
+
+What is different from running torchdiffeq's autograd graph: the attempt loop runs under ``no_grad`` and only the accepted
+steps' (t_n, dt_n, y_n, f_n) are kept; the backward re-evaluates one accepted step at a time under autograd and carries the
+two cotangents (state, FSAL derivative) down the tape -- the same discrete adjoint the HIP backward kernel implements
+(``dp_bwd_body``), O(1) graph memory instead of one graph node per stage of every step.  Step sizes are constants for
+differentiation, as in torchdiffeq (its controller runs under ``no_grad``).
+
+Semantics kept: time in float64, state / stages in the state dtype with the tableau rounded to it;
+stage times formed in the state dtype; stages with alpha == 1 evaluated at ``nextafter(t1, -inf)``; one batch-global RMS
+error ratio; ``dt *= min(10, max(0.9 ratio^(-1/5), dfactor))`` with ``dfactor = 1 if ratio < 1 else 0.2`` (x10 when the
+ratio is 0); Hairer's initial step with order 4; quartic dense output through ``y_mid``; steps are not clipped to the
+output grid; failures are ``HodeError`` (a ``RuntimeError``: non-finite state, dt underflow).
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_ALPHA = (1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
+_BETA = (
+    (1 / 5,),
+    (3 / 40, 9 / 40),
+    (44 / 45, -56 / 15, 32 / 9),
+    (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+    (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+    (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84),
+)
+_C_ERR = (35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720, -2187 / 6784 - -12231 / 42400,
+          11 / 84 - 649 / 6300, -1.0 / 60.0)
+_C_MID = (6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+          187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2)
+
+last_stats = {"n_accepted": 0, "n_rejected": 0, "nfe": 0}
+
+
+class _Tableau:
+    def __init__(self, ref):
+        cast = lambda v: torch.tensor(v, dtype=torch.float64).to(dtype=ref.dtype, device=ref.device)
+        self.np_t = np.float32 if ref.dtype == torch.float32 else np.float64
+        self.alpha = tuple(self.np_t(a) for a in _ALPHA)
+        self.beta = tuple(cast(b) for b in _BETA)
+        self.c_err = cast(_C_ERR)
+        self.c_mid = cast(_C_MID)
+
+
+def _scalar(v, ref):
+    return torch.full((), float(v), dtype=ref.dtype, device=ref.device)
+
+
+def _stage_times(tab, t0, dt, t1):
+    """Stage times 2..7 in the STATE dtype (torchdiffeq casts t0, dt, t1 to it before forming t0 + alpha dt)."""
+    f = tab.np_t
+    t0s, dts, t1s = f(t0), f(dt), f(t1)
+    return [float(np.nextafter(t1s, f(-np.inf))) if a == 1 else float(t0s + a * dts) for a in tab.alpha]
+
+
+def _attempt(func, tab, y, f0, t0, dt, t1):
+    """One attempt from (y, f0): y1, f1 (FSAL) and the stacked stage derivatives k (..., 7)."""
+    dts = _scalar(tab.np_t(dt), y)
+    ks = [f0]
+    yi = y
+    for ti, b in zip(_stage_times(tab, t0, dt, t1), tab.beta):
+        yi = y + torch.stack(ks, dim=-1).matmul(b * dts).view_as(f0)
+        ks.append(func(_scalar(ti, y), yi))
+    return yi, ks[-1], torch.stack(ks, dim=-1), dts
+
+
+def _dense_coefficients(tab, y, y1, k, dts):
+    y_mid = y + k.matmul(dts * tab.c_mid).view_as(y)
+    f0, f1 = k[..., 0], k[..., -1]
+    a = 2 * dts * (f1 - f0) - 8 * (y1 + y) + 16 * y_mid
+    b = dts * (5 * f0 - 3 * f1) + 18 * y + 14 * y1 - 32 * y_mid
+    c = dts * (f1 - 4 * f0) - 11 * y - 5 * y1 + 16 * y_mid
+    return (y, dts * f0, c, b, a)
+
+
+def _dense_eval(coef, t0, t1, tj, ref):
+    x = _scalar((tj - t0) / (t1 - t0), ref)
+    total = coef[0] + x * coef[1]
+    xp = x
+    for c in coef[2:]:
+        xp = xp * x
+        total = total + xp * c
+    return total
+
+
+def _rms(x):
+    return float(x.pow(2).mean().sqrt())
+
+
+def _initial_step(func, tab, t0, y0, f0, rtol, atol):
+    f = tab.np_t
+    scale = atol + y0.abs() * rtol
+    d0, d1 = f(_rms(y0 / scale)), f(_rms(f0 / scale))
+    h0 = f(1e-6) if (d0 < 1e-5 or d1 < 1e-5) else f(f(0.01) * d0 / d1)
+    y1 = y0 + _scalar(h0, y0) * f0
+    f1 = func(_scalar(f(t0) + h0, y0), y1)
+    d2 = f(f(_rms((f1 - f0) / scale)) / h0)
+    if d1 <= 1e-15 and d2 <= 1e-15:
+        h1 = max(f(1e-6), f(h0 * f(1e-3)))
+    else:
+        h1 = f(f(f(0.01) / max(d1, d2)) ** f(1.0 / 5.0))
+    return float(min(f(100) * h0, h1))
+
+
+def _next_dt(dt, ratio):
+    if ratio == 0:
+        return dt * 10.0
+    dfactor = 1.0 if ratio < 1 else 0.2
+    return dt * min(10.0, max(0.9 / ratio ** 0.2, dfactor))
+
+
+class _Dopri5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, func, tt, rtol, atol, max_num_steps, y0, *params):
+        tab = _Tableau(y0)
+        nfe = 0
+        with torch.no_grad():
+            y = y0.detach()
+            f0 = func(_scalar(tt[0], y), y)
+            dt = _initial_step(func, tab, tt[0], y, f0, rtol, atol)
+            nfe += 2
+            t_hi = tt[0]
+            out = [y]
+            steps = []  # accepted steps: (t0, dt, y_n, f_n, first output index, one past the last)
+            n_rej = 0
+            j = 1
+            while j < len(tt):
+                if len(steps) + n_rej >= max_num_steps:
+                    raise L.HodeError("hode dopri5: max_num_steps exceeded")
+                if not t_hi + dt > t_hi:
+                    raise L.HodeError("hode dopri5: underflow in dt %r" % dt)
+                if not bool(torch.isfinite(y).all()):
+                    raise L.HodeError("hode dopri5: non-finite values in state `y`")
+                t_new = t_hi + dt
+                y1, f1, k, dts = _attempt(func, tab, y, f0, t_hi, dt, t_new)
+                nfe += 6
+                tol = atol + rtol * torch.max(y.abs(), y1.abs())
+                ratio = abs(_rms(k.matmul(dts * tab.c_err).view_as(y) / tol))
+                if ratio <= 1:
+                    coef = _dense_coefficients(tab, y, y1, k, dts)
+                    j0 = j
+                    while j < len(tt) and tt[j] <= t_new:
+                        out.append(_dense_eval(coef, t_hi, t_new, tt[j], y))
+                        j += 1
+                    steps.append((t_hi, dt, y, f0, j0, j))
+                    t_hi, y, f0 = t_new, y1, f1
+                else:
+                    n_rej += 1
+                    if ratio != ratio:
+                        raise L.HodeError("hode dopri5: non-finite error ratio")
+                dt = _next_dt(dt, ratio)
+        last_stats.update(n_accepted=len(steps), n_rejected=n_rej, nfe=nfe)
+        ctx.func, ctx.tab, ctx.steps, ctx.tt, ctx.params = func, tab, steps, tt, params
+        return torch.stack(out, dim=0)
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        func, tab, steps, tt, params = ctx.func, ctx.tab, ctx.steps, ctx.tt, ctx.params
+        wrt = [p for p in params if p.requires_grad]
+        g_params = [torch.zeros_like(p) for p in wrt]
+        lam_y = torch.zeros_like(grad_h[0])
+        lam_f = torch.zeros_like(grad_h[0])
+        for n in range(len(steps) - 1, -1, -1):
+            t0, dt, y_n, f_n, j0, j1 = steps[n]
+            with torch.enable_grad():
+                y = y_n.detach().requires_grad_(True)
+                if n == 0:
+                    f0 = func(_scalar(t0, y), y)  # the first derivative is a function of y0 and the parameters
+                    leaves = [y]
+                else:
+                    f0 = f_n.detach().requires_grad_(True)  # k7 of step n-1: its cotangent is handed down the tape
+                    leaves = [y, f0]
+                y1, f1, k, dts = _attempt(func, tab, y, f0, t0, dt, t0 + dt)
+                total = (y1 * lam_y).sum() + (f1 * lam_f).sum()
+                if j1 > j0:
+                    coef = _dense_coefficients(tab, y, y1, k, dts)
+                    for j in range(j0, j1):
+                        total = total + (_dense_eval(coef, t0, t0 + dt, tt[j], y) * grad_h[j]).sum()
+                grads = torch.autograd.grad(total, leaves + wrt, allow_unused=True)
+            lam_y = grads[0] if grads[0] is not None else torch.zeros_like(lam_y)
+            if n > 0:
+                lam_f = grads[1] if grads[1] is not None else torch.zeros_like(lam_f)
+            for acc, g in zip(g_params, grads[len(leaves):]):
+                if g is not None:
+                    acc.add_(g)
+        grad_y0 = lam_y + grad_h[0]
+        it = iter(g_params)
+        return (None, None, None, None, None, grad_y0) + tuple(next(it) if p.requires_grad else None for p in params)
+
+
+def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, max_num_steps=2 ** 31 - 1):
+    """``h (T, B, D)`` of ``dy/dt = func(t, y)`` on the output grid ``t``; differentiable w.r.t. ``y0`` and
+    ``func.parameters()`` (``func`` is an ``nn.Module``).  Runs on the device of ``y0``."""
+    tt = [float(v) for v in t.detach().to(torch.float64).cpu()]  # the output grid, read back once
+    return _Dopri5.apply(func, tt, float(rtol), float(atol), int(max_num_steps), y0, *tuple(func.parameters()))

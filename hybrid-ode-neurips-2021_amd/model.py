@@ -222,10 +222,33 @@ class NeuralODE(nn.Module):
         if self.times is None:
             raise RuntimeError("NeuralODE: call set_action(a) before integrating")
         from hode import neural
+        if method == "dopri5":
+            return _eager_dopri5(self, y0, t, rtol, atol, options)
         if options.pop("step_size", None) is not None:
             raise hode.HodeError("hode: options['step_size'] is not supported yet")
         return neural.neural_solve(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight, self.ml_net[2].bias,
                                    t, self.dosage, self.times, method=method, perturb=bool(options.pop("perturb", False)))
+
+
+_EAGER_DOPRI5_ANNOUNCED = set()
+
+
+def _eager_dopri5(ode, y0, t, rtol, atol, options):
+    """(NeuralODE, "dopri5"): no fused adaptive kernel exists for this right-hand side.  The solve runs
+    as torch GPU launches per stage (``hode.adaptive_eager``: torchdiffeq's dopri5 semantics, discrete adjoint over the
+    accepted-step tape) -- said once per rhs class, never silently, and never on the CPU."""
+    from hode import adaptive_eager
+    if not y0.is_cuda:
+        raise hode.HodeError("hode: %s needs its tensors on a HIP device (there is no CPU path)" % type(ode).__name__)
+    name = type(ode).__name__
+    if name not in _EAGER_DOPRI5_ANNOUNCED:
+        _EAGER_DOPRI5_ANNOUNCED.add(name)
+        import warnings
+        warnings.warn("hode: %s with method='dopri5' has no fused kernel; integrating with torch GPU launches per stage "
+                      "(hode.adaptive_eager).  The fixed-grid methods (rk4, midpoint, euler) use the HIP kernels." % name)
+    for key in ("step_size", "perturb", "step_t"):  # fixed-grid options: torchdiffeq's dopri5 ignores them with a warning
+        options.pop(key, None)
+    return adaptive_eager.odeint_dopri5(ode, y0, t, rtol=rtol, atol=atol)
 
 
 class RocheExpertDecoder(nn.Module):
@@ -364,6 +387,11 @@ class RocheODEReal(nn.Module):
         if self.dosage is None:
             raise RuntimeError("RocheODEReal: call set_action_static(a, s) before integrating")
         from hode import real
+        if method == "dopri5":
+            # DecoderReal hands dopri5 a `step_t` grid (model.py:826: steps are cut at the hourly dose switches); that
+            # option's semantics are restated neither by the oracle nor by hode.adaptive_eager.  real.sh:15 uses midpoint.
+            raise hode.HodeError("hode: RocheODEReal is built for the fixed-grid methods (euler, midpoint, rk4); "
+                                 "dopri5 with options['step_t'] is not supported")
         step_size = options.pop("step_size", None)
         if step_size is not None and t.numel() > 1:
             # torchdiffeq builds its own grid t0 + k*step_size; supported when that grid IS the output grid

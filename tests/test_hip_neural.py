@@ -71,3 +71,40 @@ def test_neural_decoder_mirror_and_dose_impulse():
     assert x_hat.shape == (T, B, obs) and torch.isfinite(h).all()
     _, h0 = dec(z, torch.zeros_like(a))
     assert (h - h0).abs().max().item() > 1e-4  # the impulse at the on-grid dose time changes the trajectory
+
+
+def test_neural_dopri5_through_the_mirror():
+    """`run_simulation --method=neural` keeps the reference's default solver, dopri5 (sim_config.py:50): NeuralODE has no
+    fused adaptive kernel, the mirror integrates with `hode.adaptive_eager` on the GPU and says so once.  Same weights and
+    inputs through the CPU oracle: trajectories, step counts and gradients."""
+    import warnings
+
+    import model
+    from hode import adaptive_eager, synth
+    from oracle import vi as ovi
+    dev = _dev()
+    D, obs, T, B = 8, 40, 12, 20
+    torch.manual_seed(0)
+    model._EAGER_DOPRI5_ANNOUNCED.discard("NeuralODE")
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * synth.STEP, synth.STEP, roche=False, method="dopri5", device=dev)
+    dec_o = ovi.DecoderOracle(obs, D, (T - 1) * synth.STEP, synth.STEP, roche=False, method="dopri5")
+    dec_o.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    inp = synth.solver_inputs(B, T, D, seed=2)
+    z = inp["z0"].to(dev).requires_grad_(True)
+    zo = inp["z0"].clone().requires_grad_(True)
+    cot = torch.randn(T, B, obs)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        x_hat, h = dec(z, inp["actions"].to(dev))
+        dec(z.detach(), inp["actions"].to(dev))
+    assert sum("no fused kernel" in str(w.message) for w in seen) == 1  # announced, once
+    x_o, h_o = dec_o(zo, inp["actions"])
+    assert adaptive_eager.last_stats["n_accepted"] > 0
+    assert (h.detach().cpu() - h_o.detach()).abs().max().item() <= 5e-6
+    (x_hat * cot.to(dev)).sum().backward()
+    (x_o * cot).sum().backward()
+    assert _rel(z.grad.cpu(), zo.grad) <= 1e-4
+    for (n, p), (_, po) in zip(dec.named_parameters(), dec_o.named_parameters()):
+        if po.grad is None or float(po.grad.abs().max()) == 0.0:
+            continue
+        assert _rel(p.grad.cpu(), po.grad) <= 2e-4, n
