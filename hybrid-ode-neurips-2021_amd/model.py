@@ -184,12 +184,14 @@ class RocheODE(nn.Module):
             from hode import adaptive
             return adaptive.roche_dopri5(y0, self.theta_vector(), w, b, t, self.dosage, self.times, rtol=rtol, atol=atol,
                                          ablate=self.ablate)
-        step_size = options.pop("step_size", None)
-        if step_size is not None:
-            raise hode.HodeError("hode: options['step_size'] (sub-stepping between output times) is not supported yet")
-        return hode.roche_solve(y0, self.theta_vector(), w, b, t, self.dosage, self.times, method=method, ablate=self.ablate,
-                                perturb=bool(options.pop("perturb", False)), lanes_per_patient=self.lanes_per_patient,
-                                check_finite=self.check_finite)
+        from hode import substep
+        perturb = bool(options.pop("perturb", False))
+        theta = self.theta_vector()
+        return substep.solve_with_step_size(
+            lambda grid: hode.roche_solve(y0, theta, w, b, grid, self.dosage, self.times, method=method, ablate=self.ablate,
+                                          perturb=perturb, lanes_per_patient=self.lanes_per_patient,
+                                          check_finite=self.check_finite),
+            t, options.pop("step_size", None))
 
 
 class NeuralODE(nn.Module):
@@ -224,10 +226,12 @@ class NeuralODE(nn.Module):
         from hode import neural
         if method == "dopri5":
             return _eager_dopri5(self, y0, t, rtol, atol, options)
-        if options.pop("step_size", None) is not None:
-            raise hode.HodeError("hode: options['step_size'] is not supported yet")
-        return neural.neural_solve(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight, self.ml_net[2].bias,
-                                   t, self.dosage, self.times, method=method, perturb=bool(options.pop("perturb", False)))
+        from hode import substep
+        perturb = bool(options.pop("perturb", False))
+        return substep.solve_with_step_size(
+            lambda grid: neural.neural_solve(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight,
+                                             self.ml_net[2].bias, grid, self.dosage, self.times, method=method, perturb=perturb),
+            t, options.pop("step_size", None))
 
 
 _EAGER_DOPRI5_ANNOUNCED = set()
@@ -392,15 +396,19 @@ class RocheODEReal(nn.Module):
             # option's semantics are restated neither by the oracle nor by hode.adaptive_eager.  real.sh:15 uses midpoint.
             raise hode.HodeError("hode: RocheODEReal is built for the fixed-grid methods (euler, midpoint, rk4); "
                                  "dopri5 with options['step_t'] is not supported")
+        from hode import substep
         step_size = options.pop("step_size", None)
         if step_size is not None and t.numel() > 1:
-            # torchdiffeq builds its own grid t0 + k*step_size; supported when that grid IS the output grid
-            if not torch.allclose(t[1:] - t[:-1], torch.full_like(t[1:], float(step_size))):
-                raise hode.HodeError("hode: options['step_size'] different from the output spacing (sub-stepping) is not supported yet")
+            # torchdiffeq builds its own grid t0 + k*step_size; when that IS the output grid (run_real.py's default,
+            # ode_step_div = 1) nothing has to be interpolated
+            if torch.allclose(t[1:] - t[:-1], torch.full_like(t[1:], float(step_size))):
+                step_size = None
         options.pop("step_t", None)  # ignored by fixed-grid solvers (torchdiffeq only warns)
         theta = torch.stack([self.k_immunity, self.kel, self.kel2])
-        return real.real_solve(y0, theta, self.flat_weights(), t, self.dosage[..., 0], self.hidden_dim, method=method,
-                               perturb=bool(options.pop("perturb", False)))
+        wflat, perturb = self.flat_weights(), bool(options.pop("perturb", False))
+        return substep.solve_with_step_size(
+            lambda grid: real.real_solve(y0, theta, wflat, grid, self.dosage[..., 0], self.hidden_dim, method=method, perturb=perturb),
+            t, step_size)
 
 
 class _TallLinear(torch.autograd.Function):

@@ -135,3 +135,36 @@ def test_noise_level_sweep_loss_and_adjoint_grads(noise_level, method_name, D, r
             continue
         assert p.grad is not None, n
         assert _rel(p.grad, po.grad) <= 2e-3, (n, noise_level, _rel(p.grad, po.grad))
+
+
+@pytest.mark.parametrize("roche", [True, False])
+@pytest.mark.parametrize("step_size", [0.0625, 0.05])
+def test_odeint_step_size_option_sub_steps_like_torchdiffeq(roche, step_size):
+    """`hode.odeint(..., options={"step_size": s})` on the mirror's rhs modules: the kernels integrate torchdiffeq's own
+    grid t0 + k s and the outputs are read off it (`hode/substep.py`); vs the oracle's sub-stepping on the CPU."""
+    import hode
+    from hode import synth
+    from oracle.solvers import odeint as oracle_odeint
+    dev = _dev()
+    obs, D, T, B, step = 40, 8, 12, 37, synth.STEP
+    torch.manual_seed(4)
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * step, step, roche=roche, method="rk4", device=dev)
+    dec_o = ovi.DecoderOracle(obs, D, (T - 1) * step, step, roche=roche, method="rk4")
+    dec_o.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+    sol = synth.solver_inputs(B, T, D, seed=6)
+    z = sol["z0"].to(dev).requires_grad_(True)
+    zo = sol["z0"].clone().requires_grad_(True)
+    dec.ode.set_action(sol["actions"].to(dev))
+    dec_o.ode.set_action(sol["actions"])
+    h = hode.odeint(dec.ode, z, dec.t, method="rk4", options={"step_size": step_size})
+    h_o = oracle_odeint(dec_o.ode, zo, dec_o.t, method="rk4", options={"step_size": step_size})
+    assert h.shape == h_o.shape == (T, B, D)
+    assert (h.detach().cpu() - h_o.detach()).abs().max().item() <= 3e-5
+    cot = torch.randn(T, B, D)
+    (h * cot.to(dev)).sum().backward()
+    (h_o * cot).sum().backward()
+    assert _rel(z.grad, zo.grad) <= 1e-4
+    for (n, p), (_, po) in zip(dec.ode.named_parameters(), dec_o.ode.named_parameters()):
+        if po.grad is None or float(po.grad.abs().max()) < 1e-12:
+            continue
+        assert _rel(p.grad, po.grad) <= 2e-3, (n, _rel(p.grad, po.grad))

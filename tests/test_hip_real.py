@@ -64,9 +64,13 @@ def test_real_forward_backward_vs_oracle(D, H, method, perturb, layout, monkeypa
     assert _rel(theta.grad, torch.stack([f.k_immunity.grad, f.kel.grad, f.kel2.grad])) <= 1e-4
 
 
-def test_config5_mirror_loss_matches_cpu_oracle_pipeline():
+@pytest.mark.parametrize("ode_step_div", [1, 2, 3])
+def test_config5_mirror_loss_matches_cpu_oracle_pipeline(ode_step_div):
     """DDW-shaped tensors (obs 24, statics 11, D 20, enc 37->44, dec hidden 43, t0 24): VariationalInferenceReal.loss and
-    its gradients on the GPU vs the same modules evaluated on the CPU with the oracle solver injected (test only)."""
+    its gradients on the GPU vs the same modules evaluated on the CPU with the oracle solver injected (test only).
+    `ode_step_div` > 1 (run_real.py:51, `--ode_step_div`) makes torchdiffeq integrate on a grid finer than the outputs:
+    the kernels run over that grid and the outputs are read off it (`hode/substep.py`); 3 gives grid points that are
+    not fp32-exact fractions of the hour."""
     import copy
     import model
     dev = _dev()
@@ -76,7 +80,7 @@ def test_config5_mirror_loss_matches_cpu_oracle_pipeline():
     torch.manual_seed(3)
     cpu = torch.device("cpu")
     enc_c = model.EncoderLSTMReal(input_dim, int(input_dim * 1.2), D, output_all=False, reverse=False, device=cpu)
-    dec_c = model.DecoderReal(obs, D, act, stat, hidden, T, 1, method="midpoint", ode_step_size=1.0, ode_type="hybrid", t0=t0, device=cpu)
+    dec_c = model.DecoderReal(obs, D, act, stat, hidden, T, 1, method="midpoint", ode_step_size=1.0 / ode_step_div, ode_type="hybrid", t0=t0, device=cpu)
     dec_c._odeint = oracle_odeint
     enc_g, dec_g = copy.deepcopy(enc_c).to(dev), copy.deepcopy(dec_c).to(dev)
     enc_g.device = dec_g.device = dec_g.ode.device = dev
