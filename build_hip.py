@@ -2,6 +2,7 @@
 """Build libhode.so (gfx950) in-tree with hipcc: `python build_hip.py [-j N] [--force]`."""
 import argparse
 import concurrent.futures as cf
+import hashlib
 import os
 import subprocess
 import sys
@@ -42,6 +43,19 @@ def newest_dep():
     return max(ts)
 
 
+def source_digest():
+    """sha256 over everything the library is built from (sources, ABI header, flags).  Written next to libhode.so after a
+    build; tests/test_abi.py compares, so a library left over from other sources (e.g. after `git checkout`) is caught."""
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "include", "hode.h")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip", ".h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()), RK_DIMS, DP_DIMS)).encode())
+    return h.hexdigest()
+
+
 def compile_one(name, src, extra, force, dep_time):
     obj = os.path.join(OBJ, name + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= dep_time:
@@ -74,6 +88,8 @@ def build(jobs=7, force=False, verbose=True):
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
         if verbose:
             print("  linked", os.path.relpath(OUT, ROOT), flush=True)
+    with open(OUT + ".digest", "w") as f:
+        f.write(source_digest() + "\n")
     return OUT
 
 

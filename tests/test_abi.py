@@ -120,3 +120,13 @@ def test_missing_library_fails_loudly(tmp_path):
             % (os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"), str(tmp_path / "nope.so")))
     out = subprocess.check_output([sys.executable, "-c", code]).decode()
     assert "RAISED True" in out
+
+
+def test_library_was_built_from_the_sources_in_the_tree():
+    """build_hip.py stamps libhode.so with a digest of the sources, header and flags it was built from; a library left
+    over from other sources (an experiment reverted with `git checkout`, a forgotten rebuild) must not pass as current."""
+    import build_hip
+    stamp = build_hip.OUT + ".digest"
+    assert os.path.exists(build_hip.OUT), "libhode.so missing: run `python build_hip.py`"
+    assert os.path.exists(stamp), "libhode.so has no source digest: rebuild with `python build_hip.py`"
+    assert open(stamp).read().strip() == build_hip.source_digest(), "libhode.so is stale: run `python build_hip.py`"
