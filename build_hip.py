@@ -20,6 +20,7 @@ DP_DIMS = (4, 6, 8, 12)
 # per-unit flags (measured on MI355X)
 # -fno-slp-vectorize on the split kernels: packed-fp32 pairing costs more v_mov than it saves (step 0.228 -> 0.207 ms)
 EXTRA_FLAGS = {"hode_rk_split": os.environ.get("HODE_SPLIT_FLAGS", "-fno-slp-vectorize").split()}
+DP_FLAGS = os.environ.get("HODE_DP_FLAGS", "").split()
 
 
 def units():
@@ -27,7 +28,7 @@ def units():
     for d in RK_DIMS:
         u.append(("hode_rk_d%d" % d, os.path.join(CSRC, "hode_rk_dim.hip"), ["-DHODE_DIM=%d" % d]))
     for d in DP_DIMS:
-        u.append(("hode_dp_d%d" % d, os.path.join(CSRC, "hode_dopri5_dim.hip"), ["-DHODE_DIM=%d" % d]))
+        u.append(("hode_dp_d%d" % d, os.path.join(CSRC, "hode_dopri5_dim.hip"), ["-DHODE_DIM=%d" % d] + DP_FLAGS))
     for name in ("hode_dopri5", "hode_lstm", "hode_neural", "hode_real", "hode_rk_mf", "hode_readout", "hode_rk_split", "hode_crps", "hode_mckl", "hode_neural_mf", "hode_real_mf"):
         src = os.path.join(CSRC, name + ".hip")
         if os.path.exists(src):
@@ -52,7 +53,7 @@ def source_digest():
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
-    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()), RK_DIMS, DP_DIMS)).encode())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()), DP_FLAGS, RK_DIMS, DP_DIMS)).encode())
     return h.hexdigest()
 
 
