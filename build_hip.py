@@ -20,7 +20,8 @@ DP_DIMS = (4, 6, 8, 12)
 # per-unit flags (measured on MI355X)
 # -fno-slp-vectorize on the split kernels: packed-fp32 pairing costs more v_mov than it saves (step 0.228 -> 0.207 ms)
 EXTRA_FLAGS = {"hode_rk_split": os.environ.get("HODE_SPLIT_FLAGS", "-fno-slp-vectorize").split()}
-DP_FLAGS = os.environ.get("HODE_DP_FLAGS", "").split()
+DP_FLAGS = os.environ.get("HODE_DP_FLAGS", "").split()  # experiments on the dopri5 units only; product builds: empty
+EXTRA_FLAGS["hode_dopri5"] = DP_FLAGS
 
 
 def units():

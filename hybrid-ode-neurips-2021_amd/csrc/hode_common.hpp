@@ -131,11 +131,17 @@ HODE_DEV float wave_sum_stride4(float v) {
   return v;
 }
 
-// full wave sum, result in every lane
+// full wave sum, result in every lane: four DPP row rotations, then the four row sums through SGPRs.  (Six __shfl_xor
+// steps are six dependent LDS-crossbar round trips; a dopri5 attempt does two such sums on its critical path,
+// DESIGN.md section 5.)
 HODE_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v = row_sum(v);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 HODE_DEV float nextafter_up(float x) {
