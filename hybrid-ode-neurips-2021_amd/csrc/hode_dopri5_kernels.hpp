@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "../../include/hode.h"
 #include "hode_host.hpp"
 #include "hode_lanes.hpp"
@@ -202,6 +204,40 @@ HODE_DEV void dp_init2_body(const DpArgs& a) {
   }
 }
 
+// fold_waves split in two so that the loads can be requested at kernel entry, next to everything else the attempt reads:
+// fold_issue requests the first 1 024 partials without a branch (indices clamped, masked when summed), fold_finish adds
+// them in fold_waves' order.
+struct FoldHead {
+  float v[16];
+};
+HODE_DEV FoldHead fold_issue(const float* __restrict__ part, int n_waves, int stride, int off) {
+  const int lane = threadIdx.x & 63;
+  FoldHead h;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int w = min(lane + 64 * j, n_waves - 1);
+    h.v[j] = part[(size_t)w * stride + off];
+  }
+  return h;
+}
+HODE_DEV float fold_finish(const FoldHead& h, const float* __restrict__ part, int n_waves, int stride, int off) {
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += (lane + 64 * j < n_waves) ? h.v[j] : 0.f;
+  for (int base = 64 * 16; base < n_waves; base += 64 * 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int w = base + lane + 64 * j;
+      v[j] = w < n_waves ? part[(size_t)w * stride + off] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += v[j];
+  }
+  return wave_sum(s);
+}
+
 // Step-size factor of the controller (torchdiffeq _optimal_step_size with dopri5's constants: safety .9, ifactor 10,
 // dfactor .2, order 5), in fp64 like the clock: min(10, max(0.9 ratio^(-1/5), ratio < 1 ? 1 : 0.2)); 10 when ratio == 0;
 // NaN propagates (torch.max / torch.min do).  Every wave evaluates it on every attempt, so the library pow(double) --
@@ -370,6 +406,248 @@ HODE_DEV void dp_attempt_body(const DpArgs& a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ attempt kernel, owner layout
+// Same attempt, same tape, for the quad layout (LPP = 4, D = 8 / 12) -- but nothing is replicated across the quad.  The
+// launch is bound by the ~1 750 instructions a wave issues (section 5 of DESIGN.md), and in dp_attempt_body every lane of
+// a patient's quad repeats the 252-FMA stage combinations, the error estimate and the dense output of ALL D components,
+// and all-gathers every stage derivative.  Here lane q OWNS components {q} u {4 + q MR + r}: the expert component q and
+// the learned rows it evaluates anyway (MlSlice).  Stage states, stage derivatives, the error estimate, the dense output
+// and every load / store exist only for the NO = 1 + MR owned components; the one thing a stage needs from its
+// neighbours -- the full stage state as the rhs operand -- is read through DPP quad broadcasts of the owners' registers.
+template <int D>
+struct DpOwn {
+  static constexpr int MR = (D - 4) / 4;
+  static constexpr int NO = 1 + MR;
+  // component index of owned slot s for quad position q
+  HODE_DEV static int comp(int s, int q) { return s == 0 ? q : 4 + q * MR + (s - 1); }
+  HODE_DEV static void load(const float* __restrict__ base, int q, float (&o)[NO]) {
+    o[0] = base[q];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) o[1 + r] = base[4 + q * MR + r];
+  }
+  HODE_DEV static void store(float* __restrict__ base, int q, const float (&o)[NO], bool live) {
+    if (!live) return;
+    base[q] = o[0];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) base[4 + q * MR + r] = o[1 + r];
+  }
+  // full-state component C (compile time) out of the owners' registers
+  template <int C>
+  HODE_DEV static float full(const float (&o)[NO]) {
+    if constexpr (C < 4) return quad_bcast<C>(o[0]);
+    else return quad_bcast<(C - 4) / MR>(o[1 + (C - 4) % MR]);
+  }
+};
+
+template <int D, bool ABLATE, bool HILL2, int... C>
+HODE_DEV void dp_own_rhs_impl(const RocheTheta& th, const MlSlice<D, 4>& ml, float dose, int q,
+                              const float (&Yo)[DpOwn<D>::NO], float (&ko)[DpOwn<D>::NO], std::integer_sequence<int, C...>) {
+  using Own = DpOwn<D>;
+  const float Y[D] = {Own::template full<C>(Yo)...};
+  const float dis = Y[0], ir = Y[1], imm = Y[2], d2 = Y[3];
+  float k0, k1, k2, k3;
+  if constexpr (!ABLATE) {
+    const float immp = pow_hill<HILL2>(imm, th.hc);
+    const float irp = pow_hill<HILL2>(ir, th.hp);
+    const float ecp = pow_hill<HILL2>(th.ec50, th.hp);
+    k0 = dis * th.kprog - dis * immp * th.kci - dis * ir * th.kcir;
+    k1 = dis * th.kid - ir * th.koff + dis * ir * th.kfb + div_f32(irp * th.emax, ecp + irp) - d2 * ir * th.kdexa;
+    k2 = ir * th.kim;
+    k3 = th.kel * dose - th.kel * d2;
+  } else {
+    k0 = ir;
+    k1 = -1.0f * dis * th.th1;
+    k2 = d2;
+    k3 = -1.0f * imm * th.th2;
+  }
+  ko[0] = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+#pragma unroll
+  for (int r = 0; r < Own::MR; ++r) {
+    float z = ml.b[r];
+#pragma unroll
+    for (int i = 0; i < D; ++i) z = __builtin_fmaf(ml.w[r][i], Y[i], z);
+    ko[1 + r] = tanh_f32(z);
+  }
+}
+template <int D, bool ABLATE, bool HILL2>
+HODE_DEV void dp_own_rhs(const RocheTheta& th, const MlSlice<D, 4>& ml, float dose, int q, const float (&Yo)[DpOwn<D>::NO],
+                         float (&ko)[DpOwn<D>::NO]) {
+  dp_own_rhs_impl<D, ABLATE, HILL2>(th, ml, dose, q, Yo, ko, std::make_integer_sequence<int, D>{});
+}
+
+template <int D, bool ABLATE, bool HILL2, bool K1>
+HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
+  using Own = DpOwn<D>;
+  constexpr int NO = Own::NO;
+  const int par = a.attempt & 1;
+  DpCtrl* cout = a.ctrl + (par ^ 1);
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* pin = a.partials + (size_t)(par ^ 1) * 2 * a.n_waves;
+  float* pout = a.partials + (size_t)par * 2 * a.n_waves;
+  const LaneMap<4> lm(a.B, a.ppw);
+  const int q = lm.q;
+  const size_t row = (size_t)a.B * D;
+  const size_t poff = (size_t)lm.p * D;
+  const float cnt = (float)a.B * (float)D;
+  // level 1: everything addressed by the kernel arguments alone is requested before anything is waited for
+  const FoldHead head = fold_issue(pin, a.n_waves, 2, 0);
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  MlSlice<D, 4> ml;
+  ml.load(a.w1, a.b1, q);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  const DpCtrl cin = a.ctrl[par];
+  __builtin_amdgcn_sched_barrier(0);
+  if (cin.done) {
+    if (gid == 0) *cout = cin;
+    return;
+  }
+  // level 2: addressed by the controller record; BOTH candidate states, so that the decision starts no further round trip
+  float y_old[NO], k_first[NO], y_new[NO], k_last[NO];
+  Own::load(a.tape_y + (size_t)cin.n_acc * row + poff, q, y_old);
+  Own::load(a.kbuf + poff, q, k_first);
+  Own::load(a.tape_y + (size_t)(cin.n_acc + 1) * row + poff, q, y_new);  // row n_acc + 1 <= max_steps exists
+  Own::load(a.kbuf + 6 * row + poff, q, k_last);
+  const float t_next = a.t[min(cin.j_next, a.T - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+
+  DpCtrl c = cin;
+  float y[NO], f0[NO];
+  if (cin.attempt == 0) {
+    const float d2 = div_f32(__builtin_sqrtf(fold_finish(head, pin, a.n_waves, 2, 0) / cnt), cin.h0);
+    float h1;
+    if (cin.d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, cin.h0 * 1e-3f);
+    else h1 = powf(div_f32(0.01f, fmaxf(cin.d1, d2)), 0.2f);
+    c.dt = (double)fminf(100.0f * cin.h0, h1);
+#pragma unroll
+    for (int s = 0; s < NO; ++s) {
+      y[s] = y_old[s];  // n_acc == 0
+      f0[s] = k_first[s];
+    }
+  } else {
+    const float ratio = __builtin_sqrtf(fold_finish(head, pin, a.n_waves, 2, 0) / cnt);
+    const double t1 = cin.t0 + cin.dt;
+    if (ratio <= 1.0f) {
+#pragma unroll
+      for (int s = 0; s < NO; ++s) {
+        y[s] = y_new[s];
+        f0[s] = k_last[s];  // FSAL: k7 of the accepted step
+      }
+      int j = cin.j_next;
+      if (j < a.T && (double)t_next <= t1) {
+        // quartic dense output of the accepted step on the owned components (the previous launch stored k1..k7 for it)
+        float ya[NO], k1[NO], ym[NO];
+#pragma unroll
+        for (int s = 0; s < NO; ++s) {
+          ya[s] = y_old[s];
+          k1[s] = k_first[s];
+        }
+        const float dtf = (float)cin.dt;
+#pragma unroll
+        for (int s = 0; s < NO; ++s) ym[s] = ya[s];
+        for (int m = 0; m < 7; ++m) {
+          float km[NO];
+          Own::load(a.kbuf + (size_t)m * row + poff, q, km);
+          const float w = dtf * kDpMid[m];
+#pragma unroll
+          for (int s = 0; s < NO; ++s) ym[s] = __builtin_fmaf(w, km[s], ym[s]);
+        }
+        float ca[NO], cb[NO], cc_[NO], cd[NO];
+#pragma unroll
+        for (int s = 0; s < NO; ++s) {
+          const float f0i = k1[s], f1i = f0[s], y0i = ya[s], y1i = y[s], ymi = ym[s];
+          ca[s] = 2.0f * dtf * (f1i - f0i) - 8.0f * (y1i + y0i) + 16.0f * ymi;
+          cb[s] = dtf * (5.0f * f0i - 3.0f * f1i) + 18.0f * y0i + 14.0f * y1i - 32.0f * ymi;
+          cc_[s] = dtf * (f1i - 4.0f * f0i) - 11.0f * y0i - 5.0f * y1i + 16.0f * ymi;
+          cd[s] = dtf * f0i;
+        }
+        for (; j < a.T && (double)a.t[j] <= t1; ++j) {
+          const float x = (float)(((double)a.t[j] - cin.t0) / (t1 - cin.t0));
+          const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+          float out[NO];
+#pragma unroll
+          for (int s = 0; s < NO; ++s) out[s] = (((ya[s] + x * cd[s]) + x2 * cc_[s]) + x3 * cb[s]) + x4 * ca[s];
+          Own::store(a.h + (size_t)j * row + poff, q, out, lm.live);
+        }
+      }
+      if (gid == 0) {
+        a.tape_t[cin.n_acc] = cin.t0;
+        a.tape_dt[cin.n_acc] = cin.dt;
+        a.tape_j[2 * cin.n_acc] = cin.j_next;
+        a.tape_j[2 * cin.n_acc + 1] = j;
+      }
+      c.j_next = j;
+      c.n_acc = cin.n_acc + 1;
+      c.t0 = t1;
+    } else {
+      c.n_rej = cin.n_rej + 1;
+#pragma unroll
+      for (int s = 0; s < NO; ++s) {
+        y[s] = y_old[s];
+        f0[s] = k_first[s];
+      }
+    }
+    c.dt = cin.dt * dp_step_factor(ratio);
+  }
+  c.attempt = cin.attempt + 1;
+
+  bool stop = false;
+  if (c.status) { c.done = 1; stop = true; }
+  if (!stop && c.j_next >= a.T) { c.done = 1; stop = true; }
+  if (!stop && !(c.t0 + c.dt > c.t0)) { c.status |= HODE_STATUS_DT_UNDERFLOW; c.done = 1; stop = true; }
+  if (!stop && c.n_acc >= a.max_steps) { c.status |= HODE_STATUS_MAX_STEPS; c.done = 1; stop = true; }
+  if (stop) {
+    if (gid == 0) *cout = c;
+    return;
+  }
+
+  // ---- new attempt from (y, f0) at (t0, dt), owned components only
+  const float t0f = (float)c.t0, dtf = (float)c.dt, t1f = (float)(c.t0 + c.dt);
+  float k[7][NO], Yo[NO];
+#pragma unroll
+  for (int s = 0; s < NO; ++s) k[0][s] = f0[s];
+#pragma unroll
+  for (int i = 2; i <= 7; ++i) {
+    const float ti = dp_stage_time(i, t0f, dtf, t1f);
+#pragma unroll
+    for (int s = 0; s < NO; ++s) {
+      float acc = y[s];
+#pragma unroll
+      for (int m = 0; m < i - 1; ++m) acc = __builtin_fmaf(kDpBeta[i - 2][m] * dtf, k[m][s], acc);
+      Yo[s] = acc;
+    }
+    dp_own_rhs<D, ABLATE, HILL2>(th, ml, ds.at(ti, th.kel).v, q, Yo, k[i - 1]);
+  }
+  // Yo is y1 (the last beta row is the solution weights, FSAL)
+  float se = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int s = 0; s < NO; ++s) {
+    float err = 0.f;
+#pragma unroll
+    for (int m = 0; m < 7; ++m) err = __builtin_fmaf(dtf * kDpErr[m], k[m][s], err);
+    const float tol = a.atol + a.rtol * fmaxf(__builtin_fabsf(y[s]), __builtin_fabsf(Yo[s]));
+    const float u = div_f32(err, tol);
+    se = __builtin_fmaf(u, u, se);
+    bad |= !__builtin_isfinite(y[s]);
+  }
+  se = wave_sum(lm.live ? se : 0.0f);  // every component of every live patient is owned by exactly one lane
+  if ((threadIdx.x & 63) == 0) pout[2 * (gid >> 6)] = se;
+  Own::store(a.tape_y + (size_t)(c.n_acc + 1) * row + poff, q, Yo, lm.live);
+  Own::store(a.kbuf + poff, q, k[0], lm.live);
+  Own::store(a.kbuf + 6 * row + poff, q, k[6], lm.live);
+  // k2..k6 are read back only for the dense output, i.e. when an output time lies inside this step and it is accepted
+  if ((double)(c.j_next == cin.j_next ? t_next : a.t[c.j_next]) <= c.t0 + c.dt) {
+#pragma unroll
+    for (int m = 1; m < 6; ++m) Own::store(a.kbuf + (size_t)m * row + poff, q, k[m], lm.live);
+  }
+  if (bad && lm.live) atomicOr(&cout->status, HODE_STATUS_NONFINITE);
+  if (gid == 0) {
+    cout->t0 = c.t0; cout->dt = c.dt; cout->h0 = c.h0; cout->d1 = c.d1;
+    cout->n_acc = c.n_acc; cout->n_rej = c.n_rej; cout->j_next = c.j_next; cout->done = c.done; cout->attempt = c.attempt;
+    if (c.status) atomicOr(&cout->status, c.status);
+  }
+}
+
 template <int D, int LPP, bool ABLATE, int PHASE>
 __global__ __launch_bounds__(64) void dp_fwd_kernel(DpArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
@@ -379,7 +657,11 @@ __global__ __launch_bounds__(64) void dp_fwd_kernel(DpArgs a) {
   else BODY<D, LPP, ABLATE, false, false>(a);
   if constexpr (PHASE == 0) { HODE_DP_DISPATCH(dp_init1_body) }
   else if constexpr (PHASE == 1) { HODE_DP_DISPATCH(dp_init2_body) }
-  else { HODE_DP_DISPATCH(dp_attempt_body) }
+  else if constexpr (LPP == 4) {
+    if (hill2 && a.K == 1) dp_attempt_body_own<D, ABLATE, true, true>(a);
+    else if (hill2) dp_attempt_body_own<D, ABLATE, true, false>(a);
+    else dp_attempt_body_own<D, ABLATE, false, false>(a);
+  } else { HODE_DP_DISPATCH(dp_attempt_body) }
 }
 
 // ------------------------------------------------------------------------------------------------ backward

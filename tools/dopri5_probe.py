@@ -15,10 +15,15 @@ times = (torch.nonzero((chan != 0).t())[:, 1].reshape(N, -1) * synth.STEP).float
 y0 = inp["z0"].to(dev).requires_grad_(True); wg = w.to(dev).requires_grad_(True); bg = b.to(dev).requires_grad_(True)
 t = inp["t"].to(dev)
 cot = torch.randn(T, N, D, device=dev)
-for rep in range(3):
+REPS = int(os.environ.get("REPS", "3"))
+fw, bw = [], []
+for rep in range(REPS):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     h = adaptive.roche_dopri5(y0, theta, wg, bg, t, dosage, times, rtol=1e-7, atol=1e-8)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     (h * cot).sum().backward()
     torch.cuda.synchronize(); t2 = time.perf_counter()
+    fw.append((t1 - t0) * 1e3); bw.append((t2 - t1) * 1e3)
     print("N=%d T=%d D=%d: fwd %.2f ms (%d accepted, %d rejected) bwd %.2f ms" % (N, T, D, (t1 - t0) * 1e3, adaptive.last_stats["n_accepted"], adaptive.last_stats["n_rejected"], (t2 - t1) * 1e3), flush=True)
+n_att = adaptive.last_stats["n_accepted"] + adaptive.last_stats["n_rejected"]
+print("summary: fwd min %.2f median %.2f ms = %.2f us per attempt (min), bwd min %.2f ms" % (min(fw[1:]), sorted(fw[1:])[len(fw[1:]) // 2], min(fw[1:]) / n_att * 1e3, min(bw[1:])), flush=True)
