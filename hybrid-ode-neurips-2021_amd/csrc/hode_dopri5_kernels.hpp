@@ -815,12 +815,257 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ backward, owner layout
+// dp_bwd_body with the ownership of dp_attempt_body_own: stage states, stage derivatives, the cotangents g_1..g_7,
+// lam_y / lam_f and the dense-output terms exist only for the 1 + MR components a lane owns; the rhs and its VJP read the
+// full stage state / the full u = g (1 - s^2) of the learned rows through DPP quad broadcasts.  Same tape, same partial
+// layout, same arithmetic per component (only the order of the error-free reads differs).
+template <int D, bool ABLATE, bool HILL2, bool NEED_TH, int... C>
+HODE_DEV void dp_own_vjp_impl(const RocheTheta& th, const float (&wcol)[D - 4][DpOwn<D>::NO], float ln_ec50, DoseVal dose,
+                              int q, const float (&Yo)[DpOwn<D>::NO], const float (&ko)[DpOwn<D>::NO],
+                              const float (&go)[DpOwn<D>::NO], float (&ao)[DpOwn<D>::NO], GradAcc<D, 4>& acc,
+                              std::integer_sequence<int, C...>) {
+  using Own = DpOwn<D>;
+  constexpr int MR = Own::MR, NO = Own::NO, M = D - 4;
+  const float Y[D] = {Own::template full<C>(Yo)...};
+  // ---- learned rows of this lane: u_r = g_r (1 - s_r^2); dW, db; a = W^T u on the owned components
+  float u[MR];
+#pragma unroll
+  for (int r = 0; r < MR; ++r) {
+    u[r] = go[1 + r] * __builtin_fmaf(-ko[1 + r], ko[1 + r], 1.0f);
+    acc.db[r] += u[r];
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc.dw[r][i] = __builtin_fmaf(u[r], Y[i], acc.dw[r][i]);
+  }
+  float uf[M];
+#pragma unroll
+  for (int r = 0; r < MR; ++r) {
+    uf[0 * MR + r] = quad_bcast<0>(u[r]);
+    uf[1 * MR + r] = quad_bcast<1>(u[r]);
+    uf[2 * MR + r] = quad_bcast<2>(u[r]);
+    uf[3 * MR + r] = quad_bcast<3>(u[r]);
+  }
+#pragma unroll
+  for (int s = 0; s < NO; ++s) {
+    float p = 0.f;
+#pragma unroll
+    for (int j = 0; j < M; ++j) p = __builtin_fmaf(wcol[j][s], uf[j], p);
+    ao[s] = p;
+  }
+  // ---- expert block (every lane evaluates the four entries, keeps the one it owns; dth is formed redundantly by the quad
+  // exactly as in roche_vjp, the epilogue's stride-4 sum counts every patient once)
+  const float dis = Y[0], ir = Y[1], imm = Y[2], d2 = Y[3];
+  const float g0 = quad_bcast<0>(go[0]), g1 = quad_bcast<1>(go[0]), g2 = quad_bcast<2>(go[0]), g3 = quad_bcast<3>(go[0]);
+  float e0, e1, e2, e3;
+  if constexpr (!ABLATE) {
+    const float immp = pow_hill<HILL2>(imm, th.hc);
+    const float irp = pow_hill<HILL2>(ir, th.hp);
+    const float ecp = pow_hill<HILL2>(th.ec50, th.hp);
+    const float rden = __builtin_amdgcn_rcpf(ecp + irp);
+    const float dirp = dpow_dx<HILL2>(ir, th.hp);
+    const float g0d = g0 * dis, g1d = g1 * dis, g1i = g1 * ir;
+    const float er2 = th.emax * rden * rden;
+    e0 = g0 * (th.kprog - immp * th.kci - ir * th.kcir) + g1 * (th.kid + ir * th.kfb);
+    e1 = g1 * (dis * th.kfb - th.koff + er2 * ecp * dirp - d2 * th.kdexa) - g0d * th.kcir + g2 * th.kim;
+    e2 = -(g0d * th.kci * dpow_dx<HILL2>(imm, th.hc));
+    e3 = -(g1i * th.kdexa + g3 * th.kel);
+    if constexpr (NEED_TH) {
+      acc.dth[0] -= g0d * th.kci * dpow_dp(imm, th.hc, immp);
+      const float dP = dpow_dp(ir, th.hp, irp);
+      const float dE = (th.ec50 == 0.0f && th.hp >= 0.0f) ? 0.0f : ecp * ln_ec50;
+      acc.dth[1] += g1 * er2 * (dP * ecp - irp * dE);
+      acc.dth[2] -= g1 * er2 * irp * dpow_dx<HILL2>(th.ec50, th.hp);
+      acc.dth[3] += g1 * irp * rden;
+      acc.dth[4] -= g1i * d2;
+      acc.dth[5] -= g0d * ir;
+      acc.dth[6] -= g0d * immp;
+      acc.dth[7] += g0d;
+      acc.dth[8] += g1d;
+      acc.dth[9] += g1d * ir;
+      acc.dth[10] -= g1i;
+      acc.dth[11] += g2 * ir;
+      acc.dth[12] += g3 * ((dose.v - d2) + th.kel * dose.dk);
+    }
+  } else {
+    e0 = -(th.th1 * g1);
+    e1 = g0;
+    e2 = -(th.th2 * g3);
+    e3 = g2;
+    if constexpr (NEED_TH) {
+      acc.dth[13] -= dis * g1;
+      acc.dth[14] -= imm * g3;
+    }
+  }
+  ao[0] += q == 0 ? e0 : (q == 1 ? e1 : (q == 2 ? e2 : e3));
+}
+template <int D, bool ABLATE, bool HILL2, bool NEED_TH>
+HODE_DEV void dp_own_vjp(const RocheTheta& th, const float (&wcol)[D - 4][DpOwn<D>::NO], float ln_ec50, DoseVal dose, int q,
+                         const float (&Yo)[DpOwn<D>::NO], const float (&ko)[DpOwn<D>::NO], const float (&go)[DpOwn<D>::NO],
+                         float (&ao)[DpOwn<D>::NO], GradAcc<D, 4>& acc) {
+  dp_own_vjp_impl<D, ABLATE, HILL2, NEED_TH>(th, wcol, ln_ec50, dose, q, Yo, ko, go, ao, acc,
+                                             std::make_integer_sequence<int, D>{});
+}
+
+template <int D, bool ABLATE, bool HILL2, bool NEED_TH, bool K1>
+HODE_DEV void dp_bwd_body_own(const DpArgs& a) {
+  using Own = DpOwn<D>;
+  constexpr int NO = Own::NO, MR = Own::MR, M = D - 4;
+  const LaneMap<4> lm(a.B, a.ppw);
+  const int q = lm.q;
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  MlSlice<D, 4> ml;
+  ml.load(a.w1, a.b1, q);
+  float wcol[M][NO];  // W[j][owned component]: the columns of W^T u this lane forms
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    wcol[j][0] = a.w1[j * D + q];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) wcol[j][1 + r] = a.w1[j * D + 4 + q * MR + r];
+  }
+  const float ln_ec50 = log_f32(th.ec50);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  GradAcc<D, 4> acc;
+  acc.zero();
+  const size_t row = (size_t)a.B * D;
+  const size_t poff = (size_t)lm.p * D;
+  const float live = lm.live ? 1.0f : 0.0f;
+
+  float lam_y[NO], lam_f[NO];
+#pragma unroll
+  for (int s = 0; s < NO; ++s) lam_y[s] = lam_f[s] = 0.f;
+
+  for (int n = a.n_acc - 1; n >= 0; --n) {
+    const double t0 = a.tape_t[n], dt = a.tape_dt[n];
+    const double t1 = t0 + dt;
+    const float t0f = (float)t0, dtf = (float)dt, t1f = (float)t1;
+    float k[7][NO], Ys[7][NO];
+    DoseVal dv[7];
+    Own::load(a.tape_y + (size_t)n * row + poff, q, Ys[0]);
+    const float tk1 = (n == 0) ? a.t[0] : nextafter_down(t0f);
+    dv[0] = ds.at(tk1, th.kel);
+    dp_own_rhs<D, ABLATE, HILL2>(th, ml, dv[0].v, q, Ys[0], k[0]);
+#pragma unroll
+    for (int i = 2; i <= 7; ++i) {
+      const float ti = dp_stage_time(i, t0f, dtf, t1f);
+#pragma unroll
+      for (int s = 0; s < NO; ++s) {
+        float acc_ = Ys[0][s];
+#pragma unroll
+        for (int m = 0; m < i - 1; ++m) acc_ = __builtin_fmaf(kDpBeta[i - 2][m] * dtf, k[m][s], acc_);
+        Ys[i - 1][s] = acc_;
+      }
+      dv[i - 1] = ds.at(ti, th.kel);
+      dp_own_rhs<D, ABLATE, HILL2>(th, ml, dv[i - 1].v, q, Ys[i - 1], k[i - 1]);
+    }
+
+    float g[7][NO], lam_y0[NO], lam_mid[NO];
+#pragma unroll
+    for (int s = 0; s < NO; ++s) {
+      g[6][s] = lam_f[s];
+      lam_y0[s] = 0.f;
+      lam_mid[s] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) g[m][s] = 0.f;
+    }
+    const int jlo = a.tape_j[2 * n], jhi = a.tape_j[2 * n + 1];
+    for (int j = jlo; j < jhi; ++j) {
+      const float x = (float)(((double)a.t[j] - t0) / (t1 - t0));
+      const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+      const float P0 = 1.0f - 11.0f * x2 + 18.0f * x3 - 8.0f * x4;
+      const float P1 = -5.0f * x2 + 14.0f * x3 - 8.0f * x4;
+      const float Pm = 16.0f * x2 - 32.0f * x3 + 16.0f * x4;
+      const float Q0 = dtf * (x - 4.0f * x2 + 5.0f * x3 - 2.0f * x4);
+      const float Q1 = dtf * (x2 - 3.0f * x3 + 2.0f * x4);
+      float G[NO];
+      Own::load(a.grad_h + (size_t)j * row + poff, q, G);
+#pragma unroll
+      for (int s = 0; s < NO; ++s) {
+        const float gi = G[s] * live;
+        lam_y0[s] = __builtin_fmaf(P0, gi, lam_y0[s]);
+        lam_y[s] = __builtin_fmaf(P1, gi, lam_y[s]);
+        lam_mid[s] = __builtin_fmaf(Pm, gi, lam_mid[s]);
+        g[0][s] = __builtin_fmaf(Q0, gi, g[0][s]);
+        g[6][s] = __builtin_fmaf(Q1, gi, g[6][s]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NO; ++s) {
+      lam_y0[s] += lam_mid[s];
+#pragma unroll
+      for (int m = 0; m < 7; ++m) g[m][s] = __builtin_fmaf(dtf * kDpMid[m], lam_mid[s], g[m][s]);
+    }
+    float a_[NO];
+    dp_own_vjp<D, ABLATE, HILL2, NEED_TH>(th, wcol, ln_ec50, dv[6], q, Ys[6], k[6], g[6], a_, acc);
+#pragma unroll
+    for (int s = 0; s < NO; ++s) lam_y[s] += a_[s];
+#pragma unroll
+    for (int s = 0; s < NO; ++s) {
+      lam_y0[s] += lam_y[s];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) g[m][s] = __builtin_fmaf(kDpBeta[5][m] * dtf, lam_y[s], g[m][s]);
+    }
+#pragma unroll
+    for (int st = 6; st >= 2; --st) {
+      dp_own_vjp<D, ABLATE, HILL2, NEED_TH>(th, wcol, ln_ec50, dv[st - 1], q, Ys[st - 1], k[st - 1], g[st - 1], a_, acc);
+#pragma unroll
+      for (int s = 0; s < NO; ++s) {
+        lam_y0[s] += a_[s];
+#pragma unroll
+        for (int m = 0; m < st - 1; ++m) g[m][s] = __builtin_fmaf(kDpBeta[st - 2][m] * dtf, a_[s], g[m][s]);
+      }
+    }
+    if (n == 0) {
+      dp_own_vjp<D, ABLATE, HILL2, NEED_TH>(th, wcol, ln_ec50, dv[0], q, Ys[0], k[0], g[0], a_, acc);
+#pragma unroll
+      for (int s = 0; s < NO; ++s) lam_y0[s] += a_[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NO; ++s) {
+      lam_y[s] = lam_y0[s];
+      lam_f[s] = g[0][s];
+    }
+  }
+  {
+    float G[NO];
+    Own::load(a.grad_h + poff, q, G);
+#pragma unroll
+    for (int s = 0; s < NO; ++s) lam_y[s] = __builtin_fmaf(G[s], live, lam_y[s]);
+  }
+  Own::store(a.grad_y0 + poff, q, lam_y, lm.live);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  constexpr int P = M * D + M + kNTheta;
+  float* out = a.grad_partials + (size_t)wave * P;
+#pragma unroll
+  for (int r = 0; r < MR; ++r) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const float v = wave_sum_patients<4>(acc.dw[r][i]);
+      if (lane < 4) out[(lane * MR + r) * D + i] = v;
+    }
+    const float vb = wave_sum_patients<4>(acc.db[r]);
+    if (lane < 4) out[M * D + lane * MR + r] = vb;
+  }
+#pragma unroll
+  for (int i = 0; i < kNTheta; ++i) {
+    const float v = wave_sum_patients<4>(NEED_TH ? acc.dth[i] : 0.f);
+    if (lane == 0) out[M * D + M + i] = v;
+  }
+}
+
 template <int D, int LPP, bool ABLATE, bool NEED_TH>
 __global__ __launch_bounds__(64) void dp_bwd_kernel(DpArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
-  if (hill2 && a.K == 1) dp_bwd_body<D, LPP, ABLATE, true, NEED_TH, true>(a);
-  else if (hill2) dp_bwd_body<D, LPP, ABLATE, true, NEED_TH, false>(a);
-  else dp_bwd_body<D, LPP, ABLATE, false, NEED_TH, false>(a);
+  if constexpr (LPP == 4) {
+    if (hill2 && a.K == 1) dp_bwd_body_own<D, ABLATE, true, NEED_TH, true>(a);
+    else if (hill2) dp_bwd_body_own<D, ABLATE, true, NEED_TH, false>(a);
+    else dp_bwd_body_own<D, ABLATE, false, NEED_TH, false>(a);
+  } else {
+    if (hill2 && a.K == 1) dp_bwd_body<D, LPP, ABLATE, true, NEED_TH, true>(a);
+    else if (hill2) dp_bwd_body<D, LPP, ABLATE, true, NEED_TH, false>(a);
+    else dp_bwd_body<D, LPP, ABLATE, false, NEED_TH, false>(a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- launch helpers
