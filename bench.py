@@ -234,6 +234,12 @@ def main():
     ap.add_argument("--dopri5", action="store_true", help="also time the adaptive (dopri5) solve + adjoint at the same shape (BASELINE config 3 per GPU) as an extra field")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner on
+    # communicator creation): keep the real stdout aside for the result line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -377,7 +383,9 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(inp, wb)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
