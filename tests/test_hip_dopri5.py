@@ -176,3 +176,27 @@ def test_dopri5_owner_layout_kernel_variants(variant):
         if float(ora[k].abs().max()) < 1e-12:
             continue
         assert _rel(hip[k], ora[k]) <= tol, (variant, k, _rel(hip[k], ora[k]))
+
+
+@pytest.mark.parametrize("N,T", [(1, 6), (3, 1), (2, 2), (65, 4)])
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_dopri5_edge_shapes(N, T, lanes):
+    """One patient, a single output time (nothing to integrate), a batch one past a whole wave."""
+    dev = _dev()
+    D = 12
+    inp, f = _setup(N, T, D, seed=7) if T > 1 else _setup(N, 2, D, seed=7)
+    if T == 1:
+        inp = {"z0": inp["z0"], "actions": inp["actions"][:1] * 0, "t": inp["t"][:1]}
+    else:
+        inp["actions"].zero_()
+    cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(6))
+    hip = _hip(inp, f, dev, lanes, 1e-6, 1e-8, cot)
+    assert hip["h"].shape == (T, N, D) and torch.equal(hip["h"][0], inp["z0"])
+    if T == 1:
+        assert hip["stats"]["n_accepted"] == 0 and torch.equal(hip["gy0"], cot[0])
+        return
+    ora = _oracle(inp, f, 1e-6, 1e-8, cot)
+    assert abs(hip["stats"]["n_accepted"] - ora["stats"]["n_accepted"]) <= 1
+    assert (hip["h"] - ora["h"]).abs().max().item() <= 1e-5 * (1 + ora["h"].abs().max().item())
+    for k in ("gy0", "gw", "gb"):
+        assert _rel(hip[k], ora[k]) <= 2e-4, (k, _rel(hip[k], ora[k]))
