@@ -9,7 +9,21 @@ using hode::DpArgs;
 using hode::DpCtrl;
 using hode::DpLaunch;
 
-constexpr int kChunk = 32;  // attempts enqueued between two reads of the controller record
+// Attempts enqueued between two reads of the controller record.  Every read is a host round trip during which the GPU
+// idles (~70 us measured: 29-30 ms per solve with a fixed chunk of 32, 26.7 ms with 128 at 4 200 attempts), every attempt
+// enqueued past the end costs an early-exit launch (~1.3 us).  The chunk therefore starts small, doubles while nothing is
+// known, and then follows an estimate of what is left: attempts so far scaled by the output-grid progress j_next / T.
+constexpr int kChunkFirst = 64, kChunkMin = 32, kChunkMax = 2048;
+
+int next_chunk(int chunk, long long attempts, int j_next, int n_times) {
+  const double done = n_times > 1 ? (double)(j_next - 1) / (double)(n_times - 1) : 1.0;
+  if (done <= 0.0) return chunk * 2 > kChunkMax ? kChunkMax : chunk * 2;
+  const double left = (double)attempts * (1.0 - done) / done;
+  long long c = (long long)(0.75 * left);
+  if (c < kChunkMin) c = kChunkMin;
+  if (c > kChunkMax) c = kChunkMax;
+  return (int)c;
+}
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -113,8 +127,9 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
   int attempt = 0;
   // every attempt either accepts (<= max_steps of those) or shrinks dt by >= 5x towards underflow: a generous bound
   const long long max_attempts = 64LL * ((long long)d->max_steps + 64);
+  int chunk = kChunkFirst;
   for (;;) {
-    for (int i = 0; i < kChunk; ++i) {
+    for (int i = 0; i < chunk; ++i) {
       a.attempt = attempt++;
       if (int e = dp_dispatch_dim(d, L, a, s)) return e;
     }
@@ -128,6 +143,7 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
       host.status |= HODE_STATUS_MAX_STEPS;
       break;
     }
+    chunk = next_chunk(chunk, attempt, host.j_next, d->n_times);
   }
   *d->host_n_accepted = host.n_acc;
   if (d->host_n_rejected) *d->host_n_rejected = host.n_rej;
