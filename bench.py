@@ -318,9 +318,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueued = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    log("rank %d: %d steps in %.4f s" % (rank, args.steps, elapsed))
+    log("rank %d: %d steps in %.4f s (host had enqueued them after %.4f s)" % (rank, args.steps, elapsed, t_enqueued))
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
