@@ -27,12 +27,27 @@ int next_chunk(int chunk, long long attempts, int j_next, int n_times) {
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// Patients per wave of the dopri5 kernels: full waves.  The fixed-grid kernels spread a small batch over ~one wave per
+// SIMD (hode::patients_per_wave) because they stream h every step; an attempt launch has no such stream, its cost per
+// wave does not depend on the number of live lanes, and every extra wave is one more workgroup to dispatch and one more
+// error-norm partial for every wave of the next launch to read: 6.0-6.1 us per attempt with 16 patients per wave against
+// 6.3 with 10 at 10 000 patients (A/B, same call); the backward is indifferent.  HODE_PPW still overrides.
+int dp_patients_per_wave(const hode_solve_desc* d) {
+  const int cap = 64 / hode::choose_lpp(d);
+  if (getenv("HODE_PPW")) return hode::patients_per_wave(d->batch, hode::choose_lpp(d));
+  return cap;
+}
+int dp_n_waves(const hode_solve_desc* d) {
+  const int ppw = dp_patients_per_wave(d);
+  return (d->batch + ppw - 1) / ppw;
+}
+
 struct DpLayout {
   size_t ctrl, partials, kbuf, tape_t, tape_dt, tape_j, tape_y, grad_partials, total;
 };
 
 DpLayout dp_layout(const hode_solve_desc* d) {
-  const int nw = hode::n_waves_for(d->batch, hode::choose_lpp(d));
+  const int nw = dp_n_waves(d);
   const size_t BD = (size_t)d->batch * d->latent_dim;
   const size_t S = (size_t)(d->max_steps > 0 ? d->max_steps : 1);
   DpLayout L;
@@ -64,8 +79,8 @@ DpArgs dp_args(const hode_solve_desc* d, const DpLayout& L) {
   a.grad_h = d->grad_h; a.grad_y0 = d->grad_y0;
   a.grad_partials = (float*)(ws + L.grad_partials);
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose;
-  a.n_waves = hode::n_waves_for(d->batch, hode::choose_lpp(d));
-  a.ppw = hode::patients_per_wave(d->batch, hode::choose_lpp(d));
+  a.n_waves = dp_n_waves(d);
+  a.ppw = dp_patients_per_wave(d);
   a.max_steps = d->max_steps;
   a.rtol = (float)d->rtol; a.atol = (float)d->atol;
   return a;
