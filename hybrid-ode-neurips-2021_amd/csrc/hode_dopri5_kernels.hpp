@@ -8,7 +8,8 @@
 // a partial array that every wave of the NEXT launch folds in the same fixed order, so every lane takes the same
 // accept/reject decision without atomics or a grid barrier.  The current state y_n is the tape itself
 // (tape_y[n_acc]); a candidate y1 is written to tape_y[n_acc+1] and simply overwritten if the attempt is rejected.
-// Stage derivatives of the latest attempt live in kbuf[7][B][D] (kbuf[0] = f0 of the current state, FSAL).
+// Stage derivatives of the latest attempt live in kbuf[7][B][D] (kbuf[0] = f0 of the current state, FSAL; the owner-layout
+// attempt writes kbuf[1..5] only when an output time lies inside the step, the one case in which they are read back).
 #pragma once
 #include <hip/hip_runtime.h>
 
