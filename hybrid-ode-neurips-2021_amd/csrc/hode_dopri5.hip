@@ -77,6 +77,7 @@ DpArgs dp_args(const hode_solve_desc* d, const DpLayout& L) {
   a.tape_j = (int*)(ws + L.tape_j);
   a.tape_y = (float*)(ws + L.tape_y);
   a.grad_h = d->grad_h; a.grad_y0 = d->grad_y0;
+  a.hill2 = -1;
   a.grad_partials = (float*)(ws + L.grad_partials);
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose;
   a.n_waves = dp_n_waves(d);
@@ -138,6 +139,14 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
   L.phase = 1;
   if (int e = dp_dispatch_dim(d, L, a, s)) return e;
   L.phase = 2;
+  {
+    // which rhs specialisation the attempts run (both Hill exponents == 2 is the shipped configuration) is a property of
+    // the parameters: read the two exponents back once, under the init kernels, instead of on the device in every launch
+    float hill[2] = {0.f, 0.f};
+    if (int e = hode::hip_fail(hipMemcpyAsync(hill, d->theta, sizeof(hill), hipMemcpyDeviceToHost, s), "theta read-back")) return e;
+    if (int e = hode::hip_fail(hipStreamSynchronize(s), "theta read-back sync")) return e;
+    a.hill2 = (hill[0] == 2.0f && hill[1] == 2.0f) ? 1 : 0;
+  }
   DpCtrl host{};
   int attempt = 0;
   // every attempt either accepts (<= max_steps of those) or shrinks dt by >= 5x towards underflow: a generous bound

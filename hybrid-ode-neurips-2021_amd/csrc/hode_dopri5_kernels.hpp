@@ -49,6 +49,8 @@ struct DpArgs {
   float* __restrict__ grad_y0;
   float* __restrict__ grad_partials;  // [n_waves][P]
   int B, T, K, n_waves, max_steps, attempt, n_acc, ppw;
+  int hill2;  // -1: decide on the device from theta[0..1]; 0 / 1: decided by the host (attempt launches: one dependent
+              // scalar round trip less per launch, hode_dopri5.hip reads the two exponents back once per solve)
   float rtol, atol;
 };
 
@@ -651,7 +653,7 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
 
 template <int D, int LPP, bool ABLATE, int PHASE>
 __global__ __launch_bounds__(64) void dp_fwd_kernel(DpArgs a) {
-  const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
+  const bool hill2 = ABLATE || (a.hill2 >= 0 ? a.hill2 != 0 : (a.theta[0] == 2.0f && a.theta[1] == 2.0f));
 #define HODE_DP_DISPATCH(BODY)                                             \
   if (hill2 && a.K == 1) BODY<D, LPP, ABLATE, true, true>(a);              \
   else if (hill2) BODY<D, LPP, ABLATE, true, false>(a);                    \
