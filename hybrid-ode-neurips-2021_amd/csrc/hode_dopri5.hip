@@ -26,6 +26,9 @@ int next_chunk(int chunk, long long attempts, int j_next, int n_times) {
 }
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+constexpr size_t kInitOffset = 128;  // DpInit sits behind the two DpCtrl records
+static_assert(2 * sizeof(DpCtrl) <= kInitOffset, "controller records overlap the init record");
+static_assert(sizeof(hode::DpInit) == sizeof(hode_dopri5_init_record), "DpInit is the ABI's hode_dopri5_init_record");
 
 // Patients per wave of the dopri5 kernels: full waves.  The fixed-grid kernels spread a small batch over ~one wave per
 // SIMD (hode::patients_per_wave) because they stream h every step; an attempt launch has no such stream, its cost per
@@ -52,13 +55,13 @@ DpLayout dp_layout(const hode_solve_desc* d) {
   const size_t S = (size_t)(d->max_steps > 0 ? d->max_steps : 1);
   DpLayout L;
   size_t off = 0;
-  L.ctrl = off; off = align_up(off + 2 * sizeof(DpCtrl));
+  L.ctrl = off; off = align_up(off + kInitOffset + sizeof(hode::DpInit));  // two controller records + the DpInit record
   L.partials = off; off = align_up(off + (size_t)4 * nw * sizeof(float));
   L.kbuf = off; off = align_up(off + 7 * BD * sizeof(float));
   L.tape_t = off; off = align_up(off + S * sizeof(double));
   L.tape_dt = off; off = align_up(off + S * sizeof(double));
   L.tape_j = off; off = align_up(off + 2 * S * sizeof(int));
-  L.tape_y = off; off = align_up(off + (S + 1) * BD * sizeof(float));
+  L.tape_y = off; off = align_up(off + ((d->flags & HODE_FLAG_NO_TAPE) ? 2 : S + 1) * BD * sizeof(float));
   L.grad_partials = off; off = align_up(off + (size_t)nw * hode::n_partials(d) * sizeof(float));
   L.total = off;
   return L;
@@ -70,6 +73,7 @@ DpArgs dp_args(const hode_solve_desc* d, const DpLayout& L) {
   a.t = d->t; a.y0 = d->y0; a.dosage = d->dosage; a.dose_times = d->dose_times; a.theta = d->theta;
   a.w1 = d->w1; a.b1 = d->b1; a.h = d->h;
   a.ctrl = (DpCtrl*)(ws + L.ctrl);
+  a.init = (hode::DpInit*)(ws + L.ctrl + kInitOffset);
   a.partials = (float*)(ws + L.partials);
   a.kbuf = (float*)(ws + L.kbuf);
   a.tape_t = (double*)(ws + L.tape_t);
@@ -83,6 +87,7 @@ DpArgs dp_args(const hode_solve_desc* d, const DpLayout& L) {
   a.n_waves = dp_n_waves(d);
   a.ppw = dp_patients_per_wave(d);
   a.max_steps = d->max_steps;
+  a.ring = (d->flags & HODE_FLAG_NO_TAPE) ? 1 : 0;
   a.rtol = (float)d->rtol; a.atol = (float)d->atol;
   return a;
 }
@@ -183,6 +188,8 @@ extern "C" int hode_dopri5_bwd(const hode_solve_desc* d, void* stream) {
   if (int e = check_dp(d, true)) return e;
   if (d->flags & HODE_FLAG_OVERWRITE_GRADS)
     return hode::fail(HODE_E_UNSUPPORTED, "HODE_FLAG_OVERWRITE_GRADS is only implemented by hode_rk_bwd");
+  if (d->flags & HODE_FLAG_NO_TAPE)
+    return hode::fail(HODE_E_UNSUPPORTED, "the forward ran with HODE_FLAG_NO_TAPE: there is no tape to sweep");
   hipStream_t s = (hipStream_t)stream;
   const DpLayout lay = dp_layout(d);
   DpArgs a = dp_args(d, lay);
@@ -195,6 +202,28 @@ extern "C" int hode_dopri5_bwd(const hode_solve_desc* d, void* stream) {
   L.phase = 3;
   if (int e = dp_dispatch_dim(d, L, a, s)) return e;
   const int M = d->latent_dim - 4;
+  if (int e = hode::launch_fold_partials(a.grad_partials, a.n_waves, hode::n_partials(d), M * d->latent_dim, M, d->grad_w1,
+                                         d->grad_b1, d->grad_theta, d->need_theta_grad, s))
+    return e;
+  if (a.n_acc == 0 || (d->flags & HODE_FLAG_DETACH_FIRST_STEP)) return 0;
+  // the reference's graph differentiates dt_0 (kernels: "backward of the initial step size"); the partial array is free
+  // again once the fold above has read it (same stream)
+  L.phase = 4;
+  if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+  L.phase = 5;
+  if (int e = dp_dispatch_dim(d, L, a, s)) return e;
   return hode::launch_fold_partials(a.grad_partials, a.n_waves, hode::n_partials(d), M * d->latent_dim, M, d->grad_w1,
                                     d->grad_b1, d->grad_theta, d->need_theta_grad, s);
+}
+
+extern "C" int hode_dopri5_tape_offsets(const hode_solve_desc* d, size_t* out5) {
+  if (!d || !out5) return hode::fail(HODE_E_NULL, "descriptor / out5 is NULL");
+  if (d->struct_size != sizeof(hode_solve_desc)) return hode::fail(HODE_E_SIZE, "struct_size mismatch");
+  const DpLayout L = dp_layout(d);
+  out5[0] = L.ctrl + kInitOffset;
+  out5[1] = L.tape_t;
+  out5[2] = L.tape_dt;
+  out5[3] = L.tape_j;
+  out5[4] = L.tape_y;
+  return 0;
 }

@@ -29,6 +29,16 @@ struct DpCtrl {
   int n_acc, n_rej, j_next, done, status, attempt;
 };
 
+// What the backward needs of Hairer's initial step size (include/hode.h: hode_dopri5_init_record has the same layout).
+// torchdiffeq computes dt_0 = min(100 h0, h1) from y0, f0, f1 OUTSIDE no_grad (rk_common.py _before_integrate), so the
+// reference's loss.backward() differentiates it whenever the first attempt is the one that gets accepted.
+struct DpInit {
+  float h0, d0, d1, d2, h1;
+  int first_accepted;  // 1: attempt 0 (the one that ran with dt_0) was accepted
+  float sigma;         // backward: d loss / d dt_0 (diagnostics)
+  int pad;
+};
+
 struct DpArgs {
   const float* __restrict__ t;
   const float* __restrict__ y0;
@@ -39,6 +49,7 @@ struct DpArgs {
   const float* __restrict__ b1;
   float* __restrict__ h;
   DpCtrl* ctrl;            // [2]
+  DpInit* init;            // [1]
   float* partials;         // [2][2 * n_waves]
   float* kbuf;             // [7][B][D]
   double* tape_t;          // [max_steps]
@@ -49,6 +60,7 @@ struct DpArgs {
   float* __restrict__ grad_y0;
   float* __restrict__ grad_partials;  // [n_waves][P]
   int B, T, K, n_waves, max_steps, attempt, n_acc, ppw;
+  int ring;   // HODE_FLAG_NO_TAPE: tape_y holds two rows (current state / candidate) addressed by step parity
   int hill2;  // -1: decide on the device from theta[0..1]; 0 / 1: decided by the host (attempt launches: one dependent
               // scalar round trip less per launch, hode_dopri5.hip reads the two exponents back once per solve)
   float rtol, atol;
@@ -73,6 +85,9 @@ __device__ constexpr float kDpMid[7] = {
     F32(-2691868925.0 / 45128329728.0 / 2), F32(187940372067.0 / 1594534317056.0 / 2),
     F32(-1776094331.0 / 19743644256.0 / 2), F32(11237099.0 / 235043384.0 / 2)};
 #undef F32
+
+// row of tape_y that holds the state at the start of accepted step n
+HODE_DEV size_t dp_tape_row(const DpArgs& a, int n) { return (size_t)(a.ring ? (n & 1) : n); }
 
 template <bool K1>
 HODE_DEV DoseSched<K1> dp_load_dose(const DpArgs& a, int p) {
@@ -204,6 +219,9 @@ HODE_DEV void dp_init2_body(const DpArgs& a) {
     c.n_acc = 0; c.n_rej = 0; c.j_next = 1; c.done = (a.T <= 1) ? 1 : 0; c.status = 0; c.attempt = 0;
     a.ctrl[0] = c;
     a.ctrl[1] = c;  // defined contents for the record attempt 0 will fill (its status word is OR-ed into)
+    DpInit in{};
+    in.h0 = h0; in.d0 = d0; in.d1 = d1;
+    *a.init = in;
   }
 }
 
@@ -296,21 +314,23 @@ HODE_DEV void dp_attempt_body(const DpArgs& a) {
     if (cin.d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, cin.h0 * 1e-3f);
     else h1 = powf(div_f32(0.01f, fmaxf(cin.d1, d2)), 0.2f);
     c.dt = (double)fminf(100.0f * cin.h0, h1);
+    if (gid == 0) { a.init->d2 = d2; a.init->h1 = h1; }
     load_vec<D>(a.tape_y + poff, y);
     load_vec<D>(a.kbuf + poff, f0);
   } else {
     const float ratio = __builtin_sqrtf(fold_waves(pin, a.n_waves, 2, 0) / cnt);
     const bool accept = ratio <= 1.0f;
+    if (cin.attempt == 1 && gid == 0) a.init->first_accepted = accept ? 1 : 0;
     const double t1 = cin.t0 + cin.dt;
     if (accept) {
       // candidate becomes the state; emit every output time inside (t0, t1] from the quartic dense output
       float ya[D], k7[D];
-      load_vec<D>(a.tape_y + (size_t)(cin.n_acc + 1) * row + poff, y);
+      load_vec<D>(a.tape_y + dp_tape_row(a, cin.n_acc + 1) * row + poff, y);
       load_vec<D>(a.kbuf + 6 * row + poff, k7);
       int j = cin.j_next;
       if (j < a.T && (double)a.t[j] <= t1) {
         float k1[D], ym[D];
-        load_vec<D>(a.tape_y + (size_t)cin.n_acc * row + poff, ya);
+        load_vec<D>(a.tape_y + dp_tape_row(a, cin.n_acc) * row + poff, ya);
         load_vec<D>(a.kbuf + poff, k1);
         const float dtf = (float)cin.dt;
 #pragma unroll
@@ -353,7 +373,7 @@ HODE_DEV void dp_attempt_body(const DpArgs& a) {
       for (int i = 0; i < D; ++i) f0[i] = k7[i];
     } else {
       c.n_rej = cin.n_rej + 1;
-      load_vec<D>(a.tape_y + (size_t)cin.n_acc * row + poff, y);
+      load_vec<D>(a.tape_y + dp_tape_row(a, cin.n_acc) * row + poff, y);
       load_vec<D>(a.kbuf + poff, f0);
     }
     // controller (torchdiffeq _optimal_step_size): fp64 clock, constants of dopri5 (safety .9, ifactor 10, dfactor .2)
@@ -397,7 +417,7 @@ HODE_DEV void dp_attempt_body(const DpArgs& a) {
   }
   se = wave_sum(se * ((lm.live && lm.q == 0) ? 1.0f : 0.0f));
   if ((threadIdx.x & 63) == 0) pout[2 * (gid >> 6)] = se;
-  store_vec<D, LPP>(a.tape_y + (size_t)(c.n_acc + 1) * row + poff, Y[6], lm.q, lm.live);
+  store_vec<D, LPP>(a.tape_y + dp_tape_row(a, c.n_acc + 1) * row + poff, Y[6], lm.q, lm.live);
 #pragma unroll
   for (int m = 0; m < 7; ++m) store_vec<D, LPP>(a.kbuf + (size_t)m * row + poff, k[m], lm.q, lm.live);
   if (bad && lm.live) atomicOr(&cout->status, HODE_STATUS_NONFINITE);  // torchdiffeq asserts on the state before a step
@@ -506,9 +526,9 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
   }
   // level 2: addressed by the controller record; BOTH candidate states, so that the decision starts no further round trip
   float y_old[NO], k_first[NO], y_new[NO], k_last[NO];
-  Own::load(a.tape_y + (size_t)cin.n_acc * row + poff, q, y_old);
+  Own::load(a.tape_y + dp_tape_row(a, cin.n_acc) * row + poff, q, y_old);
   Own::load(a.kbuf + poff, q, k_first);
-  Own::load(a.tape_y + (size_t)(cin.n_acc + 1) * row + poff, q, y_new);  // row n_acc + 1 <= max_steps exists
+  Own::load(a.tape_y + dp_tape_row(a, cin.n_acc + 1) * row + poff, q, y_new);  // row n_acc + 1 <= max_steps exists
   Own::load(a.kbuf + 6 * row + poff, q, k_last);
   const float t_next = a.t[min(cin.j_next, a.T - 1)];
   __builtin_amdgcn_sched_barrier(0);
@@ -521,6 +541,7 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
     if (cin.d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, cin.h0 * 1e-3f);
     else h1 = powf(div_f32(0.01f, fmaxf(cin.d1, d2)), 0.2f);
     c.dt = (double)fminf(100.0f * cin.h0, h1);
+    if (gid == 0) { a.init->d2 = d2; a.init->h1 = h1; }
 #pragma unroll
     for (int s = 0; s < NO; ++s) {
       y[s] = y_old[s];  // n_acc == 0
@@ -529,6 +550,7 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
   } else {
     const float ratio = __builtin_sqrtf(fold_finish(head, pin, a.n_waves, 2, 0) / cnt);
     const double t1 = cin.t0 + cin.dt;
+    if (cin.attempt == 1 && gid == 0) a.init->first_accepted = ratio <= 1.0f ? 1 : 0;
     if (ratio <= 1.0f) {
 #pragma unroll
       for (int s = 0; s < NO; ++s) {
@@ -635,7 +657,7 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
   }
   se = wave_sum(lm.live ? se : 0.0f);  // every component of every live patient is owned by exactly one lane
   if ((threadIdx.x & 63) == 0) pout[2 * (gid >> 6)] = se;
-  Own::store(a.tape_y + (size_t)(c.n_acc + 1) * row + poff, q, Yo, lm.live);
+  Own::store(a.tape_y + dp_tape_row(a, c.n_acc + 1) * row + poff, q, Yo, lm.live);
   Own::store(a.kbuf + poff, q, k[0], lm.live);
   Own::store(a.kbuf + 6 * row + poff, q, k[6], lm.live);
   // k2..k6 are read back only for the dense output, i.e. when an output time lies inside this step and it is accepted
@@ -673,8 +695,40 @@ __global__ __launch_bounds__(64) void dp_fwd_kernel(DpArgs a) {
 //   lam_y0 = lam_y1 (+ dense-output terms);  g_m += dt (b_m lam_y1 + cmid_m lam_ymid)
 //   for i = 6..2: a_i = J_i^T g_i; lam_y0 += a_i; g_m += dt beta_{i,m} a_i (m < i)
 //   g1 is handed to step n-1 as lam_f (k1 of step n IS k7 of step n-1); at n = 0 it goes through J1 instead.
-// Step sizes are constants (the controller runs under no_grad in torchdiffeq); the O(tol) dependence of the FIRST
-// step size on the parameters, which torchdiffeq's graph formally contains, is not differentiated.
+// Step sizes dt_1, dt_2, ... are constants (torchdiffeq's controller runs under no_grad).  dt_0 is not: Hairer's initial
+// step is computed from y0, f0, f1 with autograd on, and when attempt 0 is accepted every later step boundary is
+// t_n = t[0] + dt_0 + const.  The sweep therefore also accumulates sigma = d loss / d dt_0 (this lane's share):
+//   all steps:  stage times    g_i[3] * (-kel^2 Dose(tau_i)) * d tau_i / d dt_0     (the rhs depends on t through the dose
+//                              only; d tau_i / d dt_0 = 1 for n >= 1, alpha_i for the stages of step 0)
+//               dense output   G_j . p'(x_j) * d x_j / d dt_0,  x = (t_j - t_n) / dt_n:  -1/dt_n (n >= 1), -x/dt_0 (n = 0)
+//   step 0:     dt_0 itself    a_i . (Y_i - y0)/dt + lam_y1 . (y1 - y0)/dt + lam_mid . (y_mid - y0)/dt
+//                              + (sum_j Q0_j G_j . f0 + sum_j Q1_j G_j . f1)/dt
+// (formulas checked against autograd in fp64; the replay oracle of tests/test_hip_dopri5.py pins the sum).  The kernels
+// dp_initbwd_* below push sigma through dt_0 = min(100 h0, h1) into grad_y0 and the parameter gradients.
+template <int D, int LPP, bool NEED_TH>
+HODE_DEV void dp_store_grad_partials(const GradAcc<D, LPP>& acc, float* __restrict__ out) {
+  constexpr int M = D - 4;
+  constexpr int MR = MlSlice<D, LPP>::MR;
+  const int lane = threadIdx.x & 63;
+  if constexpr (M > 0) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float v = wave_sum_patients<LPP>(acc.dw[r][i]);
+        if (lane < LPP) out[(lane * MR + r) * D + i] = v;
+      }
+      const float vb = wave_sum_patients<LPP>(acc.db[r]);
+      if (lane < LPP) out[M * D + lane * MR + r] = vb;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kNTheta; ++i) {
+    const float v = wave_sum_patients<LPP>(NEED_TH ? acc.dth[i] : 0.f);
+    if (lane == 0) out[M * D + M + i] = v;
+  }
+}
+
 template <int D, int LPP, bool ABLATE, bool HILL2, bool NEED_TH, bool K1>
 HODE_DEV void dp_bwd_body(const DpArgs& a) {
   using Ml = MlSlice<D, LPP>;
@@ -697,11 +751,15 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
   float lam_y[D], lam_f[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) lam_y[i] = lam_f[i] = 0.f;
+  float sig_t = 0.f, sig_d = 0.f;  // sigma = -kel^2 sig_t + sig_d
 
   for (int n = a.n_acc - 1; n >= 0; --n) {
     const double t0 = a.tape_t[n], dt = a.tape_dt[n];
     const double t1 = t0 + dt;
     const float t0f = (float)t0, dtf = (float)dt, t1f = (float)t1;
+    const bool first = n == 0;
+    const float rdt = div_f32(1.0f, dtf);
+    float sd = 0.f;  // this step's terms that carry 1/dt
     float y0[D];
     load_vec<D>(a.tape_y + (size_t)n * row + poff, y0);
     float k[7][D], Y[7][D], s[7][MR];
@@ -724,24 +782,58 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
     }
     // cotangents of the outputs interpolated inside this step
     const int jlo = a.tape_j[2 * n], jhi = a.tape_j[2 * n + 1];
-    for (int j = jlo; j < jhi; ++j) {
-      const float x = (float)(((double)a.t[j] - t0) / (t1 - t0));
-      const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
-      const float P0 = 1.0f - 11.0f * x2 + 18.0f * x3 - 8.0f * x4;
-      const float P1 = -5.0f * x2 + 14.0f * x3 - 8.0f * x4;
-      const float Pm = 16.0f * x2 - 32.0f * x3 + 16.0f * x4;
-      const float Q0 = dtf * (x - 4.0f * x2 + 5.0f * x3 - 2.0f * x4);
-      const float Q1 = dtf * (x2 - 3.0f * x3 + 2.0f * x4);
-      float G[D];
-      load_vec<D>(a.grad_h + (size_t)j * row + poff, G);
+    if (jlo < jhi) {
+      // p'(x) / dt of this step's dense-output polynomial.  With y1 = y0 + dt S1, y_mid = y0 + dt Sm the y0 terms of the
+      // quartic's coefficients cancel exactly (-8 - 8 + 16 = 18 + 14 - 32 = -11 - 5 + 16 = 0), so the coefficients are dt
+      // times combinations of the stage derivatives -- formed from those directly: differencing the O(1) states of a
+      // step of size 1e-4 and dividing by dt again would leave percent-level noise in sigma.
+      float cd[D], cc_[D], cb[D], ca[D], ymd[D];
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        const float gi = G[i] * live;
-        lam_y0[i] = __builtin_fmaf(P0, gi, lam_y0[i]);
-        lam_y[i] = __builtin_fmaf(P1, gi, lam_y[i]);
-        lam_mid[i] = __builtin_fmaf(Pm, gi, lam_mid[i]);
-        g[0][i] = __builtin_fmaf(Q0, gi, g[0][i]);
-        g[6][i] = __builtin_fmaf(Q1, gi, g[6][i]);
+        float s1 = 0.f, sm = 0.f;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) s1 = __builtin_fmaf(kDpBeta[5][m], k[m][i], s1);
+#pragma unroll
+        for (int m = 0; m < 7; ++m) sm = __builtin_fmaf(kDpMid[m], k[m][i], sm);
+        const float f0i = k[0][i], f1i = k[6][i];
+        ca[i] = 4.0f * (2.0f * (f1i - f0i) - 8.0f * s1 + 16.0f * sm);
+        cb[i] = 3.0f * ((5.0f * f0i - 3.0f * f1i) + 14.0f * s1 - 32.0f * sm);
+        cc_[i] = 2.0f * ((f1i - 4.0f * f0i) - 5.0f * s1 + 16.0f * sm);
+        cd[i] = f0i;
+        ymd[i] = sm;  // (y_mid - y0) / dt
+      }
+      for (int j = jlo; j < jhi; ++j) {
+        const float x = (float)(((double)a.t[j] - t0) / (t1 - t0));
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+        const float P0 = 1.0f - 11.0f * x2 + 18.0f * x3 - 8.0f * x4;
+        const float P1 = -5.0f * x2 + 14.0f * x3 - 8.0f * x4;
+        const float Pm = 16.0f * x2 - 32.0f * x3 + 16.0f * x4;
+        const float Q0 = dtf * (x - 4.0f * x2 + 5.0f * x3 - 2.0f * x4);
+        const float Q1 = dtf * (x2 - 3.0f * x3 + 2.0f * x4);
+        const float xs = first ? -x : -1.0f;  // d x / d dt_0 times dt
+        float G[D];
+        load_vec<D>(a.grad_h + (size_t)j * row + poff, G);
+        float sx = 0.f;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const float gi = G[i] * live;
+          lam_y0[i] = __builtin_fmaf(P0, gi, lam_y0[i]);
+          lam_y[i] = __builtin_fmaf(P1, gi, lam_y[i]);
+          lam_mid[i] = __builtin_fmaf(Pm, gi, lam_mid[i]);
+          g[0][i] = __builtin_fmaf(Q0, gi, g[0][i]);
+          g[6][i] = __builtin_fmaf(Q1, gi, g[6][i]);
+          const float dp = cd[i] + x * cc_[i] + x2 * cb[i] + x3 * ca[i];  // p'(x) / dt
+          sx = __builtin_fmaf(gi, dp, sx);
+        }
+        sig_d = __builtin_fmaf(xs, sx, sig_d);
+      }
+      if (first) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          sd = __builtin_fmaf(g[0][i], k[0][i], sd);               // g[0] holds sum_j Q0_j G_j so far
+          sd = __builtin_fmaf(g[6][i] - lam_f[i], k[6][i], sd);    // sum_j Q1_j G_j
+          sig_d = __builtin_fmaf(lam_mid[i], ymd[i], sig_d);
+        }
       }
     }
     // y_mid = y0 + dt sum cmid_m k_m
@@ -754,12 +846,14 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
     // stage 7: k7 = f(t1-, y1)
     float a_[D];
     roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, mc, ln_ec50, dv[6], Y[6], s[6], g[6], lm.q, a_, acc);
+    if constexpr (!ABLATE) sig_t = __builtin_fmaf(g[6][3], dv[6].v, sig_t);  // alpha_7 = 1 in every step
 #pragma unroll
     for (int i = 0; i < D; ++i) lam_y[i] += a_[i];
     // y1 = y0 + dt sum_{m<=6} beta_6m k_m
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       lam_y0[i] += lam_y[i];
+      if (first) sd = __builtin_fmaf(lam_y[i], Y[6][i] - y0[i], sd);
 #pragma unroll
       for (int m = 0; m < 6; ++m) g[m][i] = __builtin_fmaf(kDpBeta[5][m] * dtf, lam_y[i], g[m][i]);
     }
@@ -768,9 +862,11 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
     for (int st = 6; st >= 2; --st) {
       roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, mc, ln_ec50, dv[st - 1], Y[st - 1], s[st - 1], g[st - 1], lm.q,
                                                 a_, acc);
+      if constexpr (!ABLATE) sig_t = __builtin_fmaf(g[st - 1][3] * (first ? kDpAlpha[st - 2] : 1.0f), dv[st - 1].v, sig_t);
 #pragma unroll
       for (int i = 0; i < D; ++i) {
         lam_y0[i] += a_[i];
+        if (first) sd = __builtin_fmaf(a_[i], Y[st - 1][i] - y0[i], sd);
 #pragma unroll
         for (int m = 0; m < st - 1; ++m) g[m][i] = __builtin_fmaf(kDpBeta[st - 2][m] * dtf, a_[i], g[m][i]);
       }
@@ -785,6 +881,13 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
       lam_y[i] = lam_y0[i];
       lam_f[i] = g[0][i];
     }
+    sig_d = __builtin_fmaf(sd, rdt, sig_d);
+  }
+  {
+    // every lane of a patient's quad holds the full vectors: count the patient once
+    const float mine = (LPP == 1 || lm.q == 0) ? 1.0f : 0.0f;
+    const float sig = wave_sum(mine * __builtin_fmaf(-th.kel * th.kel, sig_t, sig_d));
+    if ((threadIdx.x & 63) == 0) a.partials[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = sig;
   }
   // output 0 is y0 itself
   {
@@ -795,27 +898,9 @@ HODE_DEV void dp_bwd_body(const DpArgs& a) {
   }
   store_vec<D, LPP>(a.grad_y0 + poff, lam_y, lm.q, lm.live);
 
-  const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   constexpr int P = M * D + M + kNTheta;
-  float* out = a.grad_partials + (size_t)wave * P;
-  if constexpr (M > 0) {
-#pragma unroll
-    for (int r = 0; r < MR; ++r) {
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        const float v = wave_sum_patients<LPP>(acc.dw[r][i]);
-        if (lane < LPP) out[(lane * MR + r) * D + i] = v;
-      }
-      const float vb = wave_sum_patients<LPP>(acc.db[r]);
-      if (lane < LPP) out[M * D + lane * MR + r] = vb;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < kNTheta; ++i) {
-    const float v = wave_sum_patients<LPP>(NEED_TH ? acc.dth[i] : 0.f);
-    if (lane == 0) out[M * D + M + i] = v;
-  }
+  dp_store_grad_partials<D, LPP, NEED_TH>(acc, a.grad_partials + (size_t)wave * P);
 }
 
 // ------------------------------------------------------------------------------------------ backward, owner layout
@@ -936,11 +1021,16 @@ HODE_DEV void dp_bwd_body_own(const DpArgs& a) {
   float lam_y[NO], lam_f[NO];
 #pragma unroll
   for (int s = 0; s < NO; ++s) lam_y[s] = lam_f[s] = 0.f;
+  float sig_t = 0.f, sig_d = 0.f;     // d loss / d dt_0 = -kel^2 sig_t + sig_d, see dp_bwd_body
+  const float own3 = q == 3 ? 1.0f : 0.0f;  // the lane that owns Dose2, the one component whose rhs depends on t
 
   for (int n = a.n_acc - 1; n >= 0; --n) {
     const double t0 = a.tape_t[n], dt = a.tape_dt[n];
     const double t1 = t0 + dt;
     const float t0f = (float)t0, dtf = (float)dt, t1f = (float)t1;
+    const bool first = n == 0;
+    const float rdt = div_f32(1.0f, dtf);
+    float sd = 0.f;
     float k[7][NO], Ys[7][NO];
     DoseVal dv[7];
     Own::load(a.tape_y + (size_t)n * row + poff, q, Ys[0]);
@@ -971,24 +1061,54 @@ HODE_DEV void dp_bwd_body_own(const DpArgs& a) {
       for (int m = 0; m < 6; ++m) g[m][s] = 0.f;
     }
     const int jlo = a.tape_j[2 * n], jhi = a.tape_j[2 * n + 1];
-    for (int j = jlo; j < jhi; ++j) {
-      const float x = (float)(((double)a.t[j] - t0) / (t1 - t0));
-      const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
-      const float P0 = 1.0f - 11.0f * x2 + 18.0f * x3 - 8.0f * x4;
-      const float P1 = -5.0f * x2 + 14.0f * x3 - 8.0f * x4;
-      const float Pm = 16.0f * x2 - 32.0f * x3 + 16.0f * x4;
-      const float Q0 = dtf * (x - 4.0f * x2 + 5.0f * x3 - 2.0f * x4);
-      const float Q1 = dtf * (x2 - 3.0f * x3 + 2.0f * x4);
-      float G[NO];
-      Own::load(a.grad_h + (size_t)j * row + poff, q, G);
+    if (jlo < jhi) {
+      float cd[NO], cc_[NO], cb[NO], ca[NO], ymd[NO];  // p'(x) / dt from the stage derivatives, see dp_bwd_body
 #pragma unroll
       for (int s = 0; s < NO; ++s) {
-        const float gi = G[s] * live;
-        lam_y0[s] = __builtin_fmaf(P0, gi, lam_y0[s]);
-        lam_y[s] = __builtin_fmaf(P1, gi, lam_y[s]);
-        lam_mid[s] = __builtin_fmaf(Pm, gi, lam_mid[s]);
-        g[0][s] = __builtin_fmaf(Q0, gi, g[0][s]);
-        g[6][s] = __builtin_fmaf(Q1, gi, g[6][s]);
+        float s1 = 0.f, sm = 0.f;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) s1 = __builtin_fmaf(kDpBeta[5][m], k[m][s], s1);
+#pragma unroll
+        for (int m = 0; m < 7; ++m) sm = __builtin_fmaf(kDpMid[m], k[m][s], sm);
+        const float f0i = k[0][s], f1i = k[6][s];
+        ca[s] = 4.0f * (2.0f * (f1i - f0i) - 8.0f * s1 + 16.0f * sm);
+        cb[s] = 3.0f * ((5.0f * f0i - 3.0f * f1i) + 14.0f * s1 - 32.0f * sm);
+        cc_[s] = 2.0f * ((f1i - 4.0f * f0i) - 5.0f * s1 + 16.0f * sm);
+        cd[s] = f0i;
+        ymd[s] = sm;
+      }
+      for (int j = jlo; j < jhi; ++j) {
+        const float x = (float)(((double)a.t[j] - t0) / (t1 - t0));
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+        const float P0 = 1.0f - 11.0f * x2 + 18.0f * x3 - 8.0f * x4;
+        const float P1 = -5.0f * x2 + 14.0f * x3 - 8.0f * x4;
+        const float Pm = 16.0f * x2 - 32.0f * x3 + 16.0f * x4;
+        const float Q0 = dtf * (x - 4.0f * x2 + 5.0f * x3 - 2.0f * x4);
+        const float Q1 = dtf * (x2 - 3.0f * x3 + 2.0f * x4);
+        const float xs = first ? -x : -1.0f;
+        float G[NO];
+        Own::load(a.grad_h + (size_t)j * row + poff, q, G);
+        float sx = 0.f;
+#pragma unroll
+        for (int s = 0; s < NO; ++s) {
+          const float gi = G[s] * live;
+          lam_y0[s] = __builtin_fmaf(P0, gi, lam_y0[s]);
+          lam_y[s] = __builtin_fmaf(P1, gi, lam_y[s]);
+          lam_mid[s] = __builtin_fmaf(Pm, gi, lam_mid[s]);
+          g[0][s] = __builtin_fmaf(Q0, gi, g[0][s]);
+          g[6][s] = __builtin_fmaf(Q1, gi, g[6][s]);
+          const float dp = cd[s] + x * cc_[s] + x2 * cb[s] + x3 * ca[s];
+          sx = __builtin_fmaf(gi, dp, sx);
+        }
+        sig_d = __builtin_fmaf(xs, sx, sig_d);
+      }
+      if (first) {
+#pragma unroll
+        for (int s = 0; s < NO; ++s) {
+          sd = __builtin_fmaf(g[0][s], k[0][s], sd);
+          sd = __builtin_fmaf(g[6][s] - lam_f[s], k[6][s], sd);
+          sig_d = __builtin_fmaf(lam_mid[s], ymd[s], sig_d);
+        }
       }
     }
 #pragma unroll
@@ -999,20 +1119,25 @@ HODE_DEV void dp_bwd_body_own(const DpArgs& a) {
     }
     float a_[NO];
     dp_own_vjp<D, ABLATE, HILL2, NEED_TH>(th, wcol, ln_ec50, dv[6], q, Ys[6], k[6], g[6], a_, acc);
+    if constexpr (!ABLATE) sig_t = __builtin_fmaf(g[6][0] * own3, dv[6].v, sig_t);
 #pragma unroll
     for (int s = 0; s < NO; ++s) lam_y[s] += a_[s];
 #pragma unroll
     for (int s = 0; s < NO; ++s) {
       lam_y0[s] += lam_y[s];
+      if (first) sd = __builtin_fmaf(lam_y[s], Ys[6][s] - Ys[0][s], sd);
 #pragma unroll
       for (int m = 0; m < 6; ++m) g[m][s] = __builtin_fmaf(kDpBeta[5][m] * dtf, lam_y[s], g[m][s]);
     }
 #pragma unroll
     for (int st = 6; st >= 2; --st) {
       dp_own_vjp<D, ABLATE, HILL2, NEED_TH>(th, wcol, ln_ec50, dv[st - 1], q, Ys[st - 1], k[st - 1], g[st - 1], a_, acc);
+      if constexpr (!ABLATE)
+        sig_t = __builtin_fmaf(g[st - 1][0] * (first ? own3 * kDpAlpha[st - 2] : own3), dv[st - 1].v, sig_t);
 #pragma unroll
       for (int s = 0; s < NO; ++s) {
         lam_y0[s] += a_[s];
+        if (first) sd = __builtin_fmaf(a_[s], Ys[st - 1][s] - Ys[0][s], sd);
 #pragma unroll
         for (int m = 0; m < st - 1; ++m) g[m][s] = __builtin_fmaf(kDpBeta[st - 2][m] * dtf, a_[s], g[m][s]);
       }
@@ -1027,6 +1152,12 @@ HODE_DEV void dp_bwd_body_own(const DpArgs& a) {
       lam_y[s] = lam_y0[s];
       lam_f[s] = g[0][s];
     }
+    sig_d = __builtin_fmaf(sd, rdt, sig_d);
+  }
+  {
+    // every component of every live patient is owned by exactly one lane (dead lanes carry zero cotangents)
+    const float sig = wave_sum(__builtin_fmaf(-th.kel * th.kel, sig_t, sig_d));
+    if ((threadIdx.x & 63) == 0) a.partials[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = sig;
   }
   {
     float G[NO];
@@ -1036,25 +1167,9 @@ HODE_DEV void dp_bwd_body_own(const DpArgs& a) {
   }
   Own::store(a.grad_y0 + poff, q, lam_y, lm.live);
 
-  const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   constexpr int P = M * D + M + kNTheta;
-  float* out = a.grad_partials + (size_t)wave * P;
-#pragma unroll
-  for (int r = 0; r < MR; ++r) {
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const float v = wave_sum_patients<4>(acc.dw[r][i]);
-      if (lane < 4) out[(lane * MR + r) * D + i] = v;
-    }
-    const float vb = wave_sum_patients<4>(acc.db[r]);
-    if (lane < 4) out[M * D + lane * MR + r] = vb;
-  }
-#pragma unroll
-  for (int i = 0; i < kNTheta; ++i) {
-    const float v = wave_sum_patients<4>(NEED_TH ? acc.dth[i] : 0.f);
-    if (lane == 0) out[M * D + M + i] = v;
-  }
+  dp_store_grad_partials<D, 4, NEED_TH>(acc, a.grad_partials + (size_t)wave * P);
 }
 
 template <int D, int LPP, bool ABLATE, bool NEED_TH>
@@ -1071,11 +1186,146 @@ __global__ __launch_bounds__(64) void dp_bwd_kernel(DpArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------- backward of the initial step size
+// dt_0 = min(100 h0, h1) with (torchdiffeq _select_initial_step, order 4; oracle/solvers.py::_initial_step)
+//   scale = atol + |y0| rtol;  d0 = rms(y0/scale);  d1 = rms(f0/scale);  h0 = 0.01 d0/d1  (1e-6 if d0 or d1 < 1e-5)
+//   f1 = f(t0 + h0, y0 + h0 f0);  d2 = rms((f1 - f0)/scale)/h0;  h1 = (0.01/max(d1, d2))^(1/5)  (degenerate: max(1e-6, 1e-3 h0))
+// d0, d1, d2 are batch-global, so sigma = d loss / d dt_0 (folded from the sweep's per-wave partials) reaches EVERY
+// patient's y0 and the parameters through f0 and f1.  The cotangent of h0 itself needs a second global sum (h0 enters
+// y1 = y0 + h0 f0 and the stage time t0 + h0 of every patient), hence two launches:
+//   PASS 1: per-wave partial of  sum_p ( y1bar . f0 + f1bar[3] (-kel^2 Dose(t0 + h0)) )      -> partials[n_waves + wave]
+//   PASS 2: everything else; grad_y0 += ..., parameter-gradient partials for a second fold.
+// Both recompute f0, y1, f1 (one attempt's worth of work per launch, once per solve).  The branch decisions are re-taken
+// from the fp32 values the forward left in the DpInit record, with the forward's own comparisons.
+template <int D, int LPP, bool ABLATE, bool HILL2, bool NEED_TH, bool K1, int PASS>
+HODE_DEV void dp_initbwd_body(const DpArgs& a) {
+  using Ml = MlSlice<D, LPP>;
+  constexpr int MR = Ml::MR;
+  constexpr int M = D - 4;
+  constexpr int P = M * D + M + kNTheta;
+  const LaneMap<LPP> lm(a.B, a.ppw);
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const DpInit in = *a.init;
+  const float sigma = fold_waves(a.partials, a.n_waves, 1, 0);
+  float* gout = a.grad_partials + (size_t)wave * P;
+  if (!in.first_accepted || sigma == 0.0f) {
+    // dt_0 never reached the outputs (attempt 0 rejected: every later step size is a controller constant)
+    if constexpr (PASS == 1) {
+      if (lane == 0) a.partials[a.n_waves + wave] = 0.f;
+    } else {
+      for (int i = lane; i < P; i += 64) gout[i] = 0.f;
+      if (wave == 0 && lane == 0) a.init->sigma = in.first_accepted ? sigma : 0.f;
+    }
+    return;
+  }
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  Ml ml;
+  ml.load(a.w1, a.b1, lm.q);
+  MlColSlice<D, LPP> mc;
+  mc.load(a.w1, lm.q);
+  const float ln_ec50 = log_f32(th.ec50);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  GradAcc<D, LPP> acc;
+  acc.zero();
+  const float live = lm.live ? 1.0f : 0.0f;
+  const float NN = (float)a.B * (float)D;
+
+  // ---- scalar part of the chain (identical in every lane)
+  const float h0 = in.h0, d0 = in.d0, d1 = in.d1, d2 = in.d2, h1 = in.h1;
+  const bool deg0 = d0 < 1e-5f || d1 < 1e-5f;
+  const bool deg1 = d1 <= 1e-15f && d2 <= 1e-15f;
+  const bool use_d2 = d2 > d1;                 // python max(d1, d2) keeps d1 unless d2 > d1
+  const bool branch_a = 100.0f * h0 <= h1;     // dt_0 = 100 h0
+  float h0b = branch_a ? 100.0f * sigma : 0.0f;
+  const float h1b = branch_a ? 0.0f : sigma;
+  float d1b = 0.f, d2b = 0.f;
+  if (deg1) {
+    if (h0 * 1e-3f > 1e-6f) h0b = __builtin_fmaf(1e-3f, h1b, h0b);
+  } else {
+    const float mb = -0.2f * div_f32(h1, use_d2 ? d2 : d1) * h1b;
+    if (use_d2) d2b = mb; else d1b = mb;
+  }
+  const float r2 = d2 * h0;  // rms((f1 - f0)/scale)
+  float r2b = 0.f;
+  if (d2b != 0.0f && r2 > 0.0f) {
+    r2b = div_f32(d2b, h0);
+    h0b -= div_f32(d2b * d2, h0);
+  }
+
+  // ---- per patient: recompute f0, y1, f1
+  float y[D], f0[D], y1[D], f1[D], own0[MR], own1[MR];
+  load_vec<D>(a.y0 + (size_t)lm.p * D, y);
+  const float t0f = a.t[0];
+  const DoseVal dv0 = ds.at(t0f, th.kel);
+  roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dv0.v, y, f0, own0);
+#pragma unroll
+  for (int c = 0; c < D; ++c) y1[c] = __builtin_fmaf(h0, f0[c], y[c]);
+  const DoseVal dv1 = ds.at(add_rn(t0f, h0), th.kel);
+  roche_rhs<D, LPP, ABLATE, HILL2>(th, ml, dv1.v, y1, f1, own1);
+  float scale[D], w[D], wb[D], f1b[D], y1b[D];
+  const float cw = r2b != 0.0f ? div_f32(r2b, NN * r2) * live : 0.0f;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    scale[c] = a.atol + __builtin_fabsf(y[c]) * a.rtol;
+    w[c] = div_f32(f1[c] - f0[c], scale[c]);
+    wb[c] = cw * w[c];
+    f1b[c] = div_f32(wb[c], scale[c]);
+  }
+  roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, mc, ln_ec50, dv1, y1, own1, f1b, lm.q, y1b, acc);
+  const float mine = (LPP == 1 || lm.q == 0) ? 1.0f : 0.0f;
+  if constexpr (PASS == 1) {
+    float sp = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) sp = __builtin_fmaf(y1b[c], f0[c], sp);
+    if constexpr (!ABLATE) sp = __builtin_fmaf(f1b[3], -th.kel * th.kel * dv1.v, sp);
+    sp = wave_sum(sp * mine);
+    if (lane == 0) a.partials[a.n_waves + wave] = sp;
+    return;
+  } else {
+    h0b += fold_waves(a.partials + a.n_waves, a.n_waves, 1, 0);
+    float d0b = 0.f;
+    if (!deg0) {
+      d0b = div_f32(0.01f, d1) * h0b;
+      d1b -= div_f32(h0, d1) * h0b;
+    }
+    const float cv = d1 > 0.0f ? div_f32(d1b, NN * d1) * live : 0.0f;
+    const float cu = d0 > 0.0f ? div_f32(d0b, NN * d0) * live : 0.0f;
+    float f0b[D], yb[D], a0[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const float rs = div_f32(1.0f, scale[c]);
+      const float v = f0[c] * rs, u = y[c] * rs;
+      const float vb = cv * v, ub = cu * u;
+      f0b[c] = __builtin_fmaf(h0, y1b[c], (vb - wb[c]) * rs);
+      const float sb = -(wb[c] * w[c] + vb * v + ub * u) * rs;
+      const float sgn = y[c] > 0.0f ? 1.0f : (y[c] < 0.0f ? -1.0f : 0.0f);
+      yb[c] = y1b[c] + ub * rs + sb * a.rtol * sgn;
+    }
+    roche_vjp<D, LPP, ABLATE, HILL2, NEED_TH>(th, ml, mc, ln_ec50, dv0, y, own0, f0b, lm.q, a0, acc);
+    float gy[D];
+    load_vec<D>(a.grad_y0 + (size_t)lm.p * D, gy);
+#pragma unroll
+    for (int c = 0; c < D; ++c) gy[c] += yb[c] + a0[c];
+    store_vec<D, LPP>(a.grad_y0 + (size_t)lm.p * D, gy, lm.q, lm.live);
+    dp_store_grad_partials<D, LPP, NEED_TH>(acc, gout);
+    if (wave == 0 && lane == 0) a.init->sigma = sigma;
+  }
+}
+
+template <int D, int LPP, bool ABLATE, bool NEED_TH, int PASS>
+__global__ __launch_bounds__(64) void dp_initbwd_kernel(DpArgs a) {
+  const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
+  if (hill2 && a.K == 1) dp_initbwd_body<D, LPP, ABLATE, true, NEED_TH, true, PASS>(a);
+  else if (hill2) dp_initbwd_body<D, LPP, ABLATE, true, NEED_TH, false, PASS>(a);
+  else dp_initbwd_body<D, LPP, ABLATE, false, NEED_TH, false, PASS>(a);
+}
+
 // ---------------------------------------------------------------------------------------------- launch helpers
 struct DpLaunch {
   int lpp;
   bool ablate, need_th;
-  int phase;  // 0 init1, 1 init2, 2 attempt, 3 backward
+  int phase;  // 0 init1, 1 init2, 2 attempt, 3 backward sweep, 4 / 5 initial-step backward pass 1 / 2
 };
 
 template <int D, int LPP, bool ABLATE>
@@ -1089,8 +1339,16 @@ int dp_launch(const DpLaunch& L, const DpArgs& a, hipStream_t s) {
       if (L.need_th) hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, false>), grid, block, 0, s, a);
       break;
+    case 4:
+      // pass 1 only forms a scalar; its parameter accumulators are dead code in either instantiation
+      hipLaunchKernelGGL((dp_initbwd_kernel<D, LPP, ABLATE, false, 1>), grid, block, 0, s, a);
+      break;
+    case 5:
+      if (L.need_th) hipLaunchKernelGGL((dp_initbwd_kernel<D, LPP, ABLATE, true, 2>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((dp_initbwd_kernel<D, LPP, ABLATE, false, 2>), grid, block, 0, s, a);
+      break;
   }
-  return (int)hipGetLastError();
+  return hip_fail(hipGetLastError(), "dopri5 kernel launch");
 }
 
 template <int D>

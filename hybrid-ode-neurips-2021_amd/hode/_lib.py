@@ -16,7 +16,7 @@ METHODS = {"euler": METHOD_EULER, "midpoint": METHOD_MIDPOINT, "rk4": METHOD_RK4
 N_THETA = 16
 STATUS_NONFINITE, STATUS_DT_UNDERFLOW, STATUS_MAX_STEPS = 1, 2, 4
 WS_RK_FWD, WS_RK_BWD, WS_DOPRI5_FWD, WS_DOPRI5_BWD = 0, 1, 2, 3
-FLAG_SKIP_FOLD, FLAG_OVERWRITE_GRADS, FLAG_TAPE = 1, 2, 4
+FLAG_SKIP_FOLD, FLAG_OVERWRITE_GRADS, FLAG_TAPE, FLAG_DETACH_FIRST_STEP, FLAG_NO_TAPE = 1, 2, 4, 8, 16
 
 
 class HodeError(RuntimeError):
@@ -50,6 +50,11 @@ class SolveDesc(C.Structure):
         ("host_n_accepted", C.POINTER(C.c_int32)), ("host_n_rejected", C.POINTER(C.c_int32)),
         ("workspace", _fp), ("workspace_bytes", C.c_size_t),
     ]
+
+
+class Dopri5InitRecord(C.Structure):
+    _fields_ = [("h0", C.c_float), ("d0", C.c_float), ("d1", C.c_float), ("d2", C.c_float), ("h1", C.c_float),
+                ("first_accepted", C.c_int32), ("sigma", C.c_float), ("pad", C.c_int32)]
 
 
 class LstmDesc(C.Structure):
@@ -101,6 +106,7 @@ EXPORTS = (
     ("hode_rk_bwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
     ("hode_dopri5_fwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
     ("hode_dopri5_bwd", C.c_int, (C.POINTER(SolveDesc), C.c_void_p)),
+    ("hode_dopri5_tape_offsets", C.c_int, (C.POINTER(SolveDesc), C.POINTER(C.c_size_t))),
     ("hode_readout_workspace_bytes", C.c_size_t, (C.POINTER(ReadoutDesc),)),
     ("hode_readout_sse", C.c_int, (C.POINTER(ReadoutDesc), C.c_void_p)),
     ("hode_ensemble_crps", C.c_int, (C.POINTER(CrpsDesc), C.c_void_p)),

@@ -10,8 +10,11 @@ reference's call surface integrate instead of raising.  Callers announce it once
 What is different from running torchdiffeq's autograd graph: the attempt loop runs under ``no_grad`` and only the accepted
 steps' (t_n, dt_n, y_n, f_n) are kept; the backward re-evaluates one accepted step at a time under autograd and carries the
 two cotangents (state, FSAL derivative) down the tape -- the same discrete adjoint the HIP backward kernel implements
-(``dp_bwd_body``), O(1) graph memory instead of one graph node per stage of every step.  Step sizes are constants for
-differentiation, as in torchdiffeq (its controller runs under ``no_grad``).
+(``dp_bwd_body``), O(1) graph memory instead of one graph node per stage of every step.  Step sizes dt_1, dt_2, ... are
+constants for differentiation, as in torchdiffeq (its controller runs under ``no_grad``); dt_0 -- Hairer's initial step,
+which torchdiffeq computes with autograd on -- is differentiated when attempt 0 is the accepted one: the sweep collects
+sigma = d loss / d dt_0 (dt_0 itself in step 0, the shift of every later step boundary) and pushes it through
+``_initial_step_ad`` (the same term ``hode_dopri5_bwd`` adds, csrc/hode_dopri5_kernels.hpp).
 
 Semantics kept (SURVEY.md Appendix A): time in float64, state / stages in the state dtype with the tableau rounded to it;
 stage times formed in the state dtype; stages with alpha == 1 evaluated at ``nextafter(t1, -inf)``; one batch-global RMS
@@ -111,6 +114,42 @@ def _initial_step(func, tab, t0, y0, f0, rtol, atol):
     return float(min(f(100) * h0, h1))
 
 
+def _attempt_ad(func, tab, y, f0, t0, dt):
+    """``_attempt`` with the step's start time and size as float64 0-dim TENSORS (the backward differentiates them).
+    Same fp32 stage-time arithmetic as ``_stage_times``; alpha == 1 stages at nextafter(t1, -inf) with a pass-through
+    gradient (torchdiffeq's _StitchGradient)."""
+    t0s, dts, t1s = t0.to(y.dtype), dt.to(y.dtype), (t0 + dt).to(y.dtype)
+    ks = [f0]
+    yi = y
+    for a, b in zip(tab.alpha, tab.beta):
+        if a == 1:
+            ti = t1s + (torch.nextafter(t1s.detach(), t1s.detach() - 1) - t1s.detach())
+        else:
+            ti = t0s + float(a) * dts
+        yi = y + torch.stack(ks, dim=-1).matmul(b * dts).view_as(f0)
+        ks.append(func(ti, yi))
+    return yi, ks[-1], torch.stack(ks, dim=-1), dts
+
+
+def _initial_step_ad(func, tab, t0, y0, f0, rtol, atol):
+    """Hairer's initial step as a differentiable function of ``y0`` and the parameters (through ``f0``, ``f1``): what
+    torchdiffeq's ``_select_initial_step`` leaves in the reference's autograd graph (oracle/solvers.py::_initial_step)."""
+    rms = lambda x: x.pow(2).mean().sqrt()
+    scale = atol + y0.abs() * rtol
+    d0, d1 = rms(y0 / scale), rms(f0 / scale)
+    if float(d0.detach()) < 1e-5 or float(d1.detach()) < 1e-5:
+        h0 = torch.full((), 1e-6, dtype=y0.dtype, device=y0.device)
+    else:
+        h0 = 0.01 * d0 / d1
+    f1 = func(_scalar(t0, y0) + h0, y0 + h0 * f0)
+    d2 = rms((f1 - f0) / scale) / h0
+    if float(d1.detach()) <= 1e-15 and float(d2.detach()) <= 1e-15:
+        h1 = torch.max(torch.full((), 1e-6, dtype=y0.dtype, device=y0.device), h0 * 1e-3)
+    else:
+        h1 = (0.01 / (d2 if float(d2.detach()) > float(d1.detach()) else d1)) ** (1.0 / 5.0)
+    return torch.min(100 * h0, h1)
+
+
 def _next_dt(dt, ratio):
     if ratio == 0:
         return dt * 10.0
@@ -120,7 +159,7 @@ def _next_dt(dt, ratio):
 
 class _Dopri5(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, func, tt, rtol, atol, max_num_steps, y0, *params):
+    def forward(ctx, func, tt, rtol, atol, max_num_steps, detach_first_step, y0, *params):
         tab = _Tableau(y0)
         nfe = 0
         with torch.no_grad():
@@ -132,6 +171,7 @@ class _Dopri5(torch.autograd.Function):
             out = [y]
             steps = []  # accepted steps: (t0, dt, y_n, f_n, first output index, one past the last)
             n_rej = 0
+            first_accepted = False  # attempt 0 (the one that ran with Hairer's dt_0) is on the tape
             j = 1
             while j < len(tt):
                 if len(steps) + n_rej >= max_num_steps:
@@ -151,6 +191,8 @@ class _Dopri5(torch.autograd.Function):
                     while j < len(tt) and tt[j] <= t_new:
                         out.append(_dense_eval(coef, t_hi, t_new, tt[j], y))
                         j += 1
+                    if not steps:
+                        first_accepted = n_rej == 0
                     steps.append((t_hi, dt, y, f0, j0, j))
                     t_hi, y, f0 = t_new, y1, f1
                 else:
@@ -160,6 +202,7 @@ class _Dopri5(torch.autograd.Function):
                 dt = _next_dt(dt, ratio)
         last_stats.update(n_accepted=len(steps), n_rejected=n_rej, nfe=nfe)
         ctx.func, ctx.tab, ctx.steps, ctx.tt, ctx.params = func, tab, steps, tt, params
+        ctx.first_accepted, ctx.tol, ctx.y0 = first_accepted and not detach_first_step, (rtol, atol), y0.detach()
         return torch.stack(out, dim=0)
 
     @staticmethod
@@ -169,23 +212,39 @@ class _Dopri5(torch.autograd.Function):
         g_params = [torch.zeros_like(p) for p in wrt]
         lam_y = torch.zeros_like(grad_h[0])
         lam_f = torch.zeros_like(grad_h[0])
+        sigma = 0.0  # d loss / d dt_0
+        track = ctx.first_accepted
         for n in range(len(steps) - 1, -1, -1):
             t0, dt, y_n, f_n, j0, j1 = steps[n]
             with torch.enable_grad():
                 y = y_n.detach().requires_grad_(True)
+                # time leaves: dt_0 itself in step 0; for n >= 1 the shift of the step's start, t_n = t[0] + dt_0 + const
+                tvar = torch.tensor(dt if n == 0 else 0.0, dtype=torch.float64, device=y.device, requires_grad=track)
+                t0_t = torch.tensor(t0, dtype=torch.float64, device=y.device) + (0.0 if n == 0 else tvar)
+                dt_t = tvar if n == 0 else torch.tensor(dt, dtype=torch.float64, device=y.device)
                 if n == 0:
                     f0 = func(_scalar(t0, y), y)  # the first derivative is a function of y0 and the parameters
                     leaves = [y]
                 else:
                     f0 = f_n.detach().requires_grad_(True)  # k7 of step n-1: its cotangent is handed down the tape
                     leaves = [y, f0]
-                y1, f1, k, dts = _attempt(func, tab, y, f0, t0, dt, t0 + dt)
+                y1, f1, k, dts = _attempt_ad(func, tab, y, f0, t0_t, dt_t)
                 total = (y1 * lam_y).sum() + (f1 * lam_f).sum()
                 if j1 > j0:
                     coef = _dense_coefficients(tab, y, y1, k, dts)
+                    t1_t = t0_t + dt_t
                     for j in range(j0, j1):
-                        total = total + (_dense_eval(coef, t0, t0 + dt, tt[j], y) * grad_h[j]).sum()
-                grads = torch.autograd.grad(total, leaves + wrt, allow_unused=True)
+                        x = ((tt[j] - t0_t) / (t1_t - t0_t)).to(y.dtype)
+                        out, xp = coef[0] + x * coef[1], x
+                        for c in coef[2:]:
+                            xp = xp * x
+                            out = out + xp * c
+                        total = total + (out * grad_h[j]).sum()
+                grads = torch.autograd.grad(total, leaves + wrt + ([tvar] if track else []), allow_unused=True)
+            if track:
+                if grads[-1] is not None:
+                    sigma += float(grads[-1])
+                grads = grads[:-1]
             lam_y = grads[0] if grads[0] is not None else torch.zeros_like(lam_y)
             if n > 0:
                 lam_f = grads[1] if grads[1] is not None else torch.zeros_like(lam_f)
@@ -193,12 +252,27 @@ class _Dopri5(torch.autograd.Function):
                 if g is not None:
                     acc.add_(g)
         grad_y0 = lam_y + grad_h[0]
+        last_stats["sigma"] = sigma
+        if track and sigma != 0.0 and steps:
+            (rtol, atol) = ctx.tol
+            with torch.enable_grad():
+                y = ctx.y0.detach().requires_grad_(True)
+                f0 = func(_scalar(tt[0], y), y)
+                dt0 = _initial_step_ad(func, tab, tt[0], y, f0, rtol, atol)
+                grads = torch.autograd.grad(dt0, [y] + wrt, allow_unused=True)
+            if grads[0] is not None:
+                grad_y0 = grad_y0 + sigma * grads[0]
+            for acc, g in zip(g_params, grads[1:]):
+                if g is not None:
+                    acc.add_(sigma * g)
         it = iter(g_params)
-        return (None, None, None, None, None, grad_y0) + tuple(next(it) if p.requires_grad else None for p in params)
+        return (None, None, None, None, None, None, grad_y0) + tuple(next(it) if p.requires_grad else None for p in params)
 
 
-def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, max_num_steps=2 ** 31 - 1):
+def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, max_num_steps=2 ** 31 - 1, detach_first_step=False):
     """``h (T, B, D)`` of ``dy/dt = func(t, y)`` on the output grid ``t``; differentiable w.r.t. ``y0`` and
-    ``func.parameters()`` (``func`` is an ``nn.Module``).  Runs on the device of ``y0``."""
+    ``func.parameters()`` (``func`` is an ``nn.Module``).  Runs on the device of ``y0``.  ``detach_first_step`` treats
+    Hairer's dt_0 as a constant (torchdiffeq's graph differentiates it; the default follows torchdiffeq)."""
     tt = [float(v) for v in t.detach().to(torch.float64).cpu()]  # the output grid, read back once
-    return _Dopri5.apply(func, tt, float(rtol), float(atol), int(max_num_steps), y0, *tuple(func.parameters()))
+    return _Dopri5.apply(func, tt, float(rtol), float(atol), int(max_num_steps), bool(detach_first_step), y0,
+                         *tuple(func.parameters()))

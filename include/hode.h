@@ -67,6 +67,15 @@ extern "C" {
                             set, and hand the same, untouched buffer to both.  Costs 16 (stages-1) B per patient and grid
                             interval of extra HBM traffic in each direction; layouts without a tape ignore the flag. */
 
+#define HODE_FLAG_DETACH_FIRST_STEP 8 /* hode_dopri5_bwd: treat the first step size as a constant.  torchdiffeq computes
+                                        Hairer's dt_0 from y0, f0, f1 with autograd ON, so the reference's loss.backward()
+                                        differentiates it (every later dt is a controller constant); the default follows the
+                                        reference, this flag drops that term (diagnostics / tests that separate the two) */
+
+#define HODE_FLAG_NO_TAPE 16 /* hode_dopri5_fwd: no backward will follow (evaluation).  The accepted-state tape -- otherwise
+                               (max_steps + 1) * B * D * 4 bytes -- shrinks to two rows; max_steps then only bounds the
+                               24-byte-per-step time records.  hode_dopri5_bwd refuses a descriptor with this flag. */
+
 /* argument errors */
 #define HODE_E_NULL -1      /* a required pointer is NULL */
 #define HODE_E_SIZE -2      /* struct_size mismatch / non-positive dimension */
@@ -265,6 +274,18 @@ int hode_rk_bwd(const hode_solve_desc* desc, void* hip_stream);
  * Synchronises the stream once per chunk of attempts to read the controller record. */
 int hode_dopri5_fwd(const hode_solve_desc* desc, void* hip_stream);
 int hode_dopri5_bwd(const hode_solve_desc* desc, void* hip_stream);
+
+/* What hode_dopri5_fwd leaves in its workspace for the backward and for inspection.  out5 receives the byte offsets of:
+ * [0] a hode_dopri5_init_record, [1] tape_t double[n_accepted] (start time of accepted step n), [2] tape_dt
+ * double[n_accepted], [3] tape_j int32[2 n_accepted] (first / one-past-last output index interpolated inside step n),
+ * [4] tape_y float[n_accepted + 1][B][D] (state at the start of step n). */
+typedef struct hode_dopri5_init_record {
+  float h0, d0, d1, d2, h1;  /* Hairer's initial step selection: dt_0 = min(100 h0, h1) (torchdiffeq _select_initial_step) */
+  int32_t first_accepted;    /* 1: the attempt that ran with dt_0 was accepted, i.e. dt_0 is on the tape and carries gradient */
+  float sigma;               /* written by hode_dopri5_bwd: d loss / d dt_0 */
+  int32_t pad;
+} hode_dopri5_init_record;
+int hode_dopri5_tape_offsets(const hode_solve_desc* desc, size_t* out5);
 
 size_t hode_readout_workspace_bytes(const hode_readout_desc* desc);
 int hode_readout_sse(const hode_readout_desc* desc, void* hip_stream);

@@ -261,6 +261,7 @@ def _odeint_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, stats=Non
     out = [y0]
     n_acc = n_rej = 0
     tape = []
+    first_ok = False
     for j in range(1, len(t)):
         n_steps = 0
         while t[j] > t_hi:
@@ -273,6 +274,8 @@ def _odeint_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, stats=Non
             ratio = _rms(err / tol).abs()
             if ratio <= 1:
                 coef = _interp_fit(y, y1, k, dt, c_mid)
+                if not tape:
+                    first_ok = n_rej == 0
                 tape.append((float(t_hi.detach()), float(dt.detach())))
                 t_lo, t_hi = t_hi, t_new
                 y, fy = y1, f1
@@ -284,7 +287,60 @@ def _odeint_dopri5(func, y0, t, rtol, atol, max_num_steps=2 ** 31 - 1, stats=Non
             n_steps += 1
         out.append(_interp_eval(coef, t_lo, t_hi, t[j]))
     if stats is not None:
-        stats.update(n_accepted=n_acc, n_rejected=n_rej, nfe=f.nfe, tape=tape)
+        stats.update(n_accepted=n_acc, n_rejected=n_rej, nfe=f.nfe, tape=tape, first_attempt_accepted=first_ok)
+    return torch.stack(out, dim=0)
+
+
+def odeint_dopri5_replay(func, y0, t, rtol, atol, tape, first_attempt_accepted=True, stats=None):
+    """The accepted-step algebra of ``_odeint_dopri5`` driven along a GIVEN tape of ``(t_n, dt_n)`` pairs instead of by
+    the controller (test infrastructure: lets a parity test follow the step sequence another implementation took, so
+    that accept / reject decisions that flip on the last bit of the error norm drop out of the comparison).
+
+    What autograd sees is what it sees in ``_odeint_dopri5``: every ``dt_n`` with n >= 1 is a constant (the controller
+    runs under ``no_grad``); ``dt_0`` is Hairer's differentiable initial step when the first attempt was the one that got
+    accepted (``first_attempt_accepted``), a constant otherwise; step boundaries are ``t_{n+1} = t_n + dt_n`` and therefore
+    carry ``dt_0``'s gradient.  Values are taken from the tape, gradients from the formulas (value-stitching), so the
+    result is the gradient of torchdiffeq's graph evaluated on the tape's step sequence.
+    """
+    f = _Rhs(func)
+    dtype = y0.dtype
+    tab = (
+        tuple(float(torch.tensor(a, dtype=torch.float64).to(dtype)) for a in DP_ALPHA),
+        tuple(torch.tensor(b, dtype=torch.float64).to(dtype) for b in DP_BETA),
+        torch.tensor(DP_C_ERR, dtype=torch.float64).to(dtype),
+    )
+    c_mid = torch.tensor(DP_C_MID, dtype=torch.float64).to(dtype)
+    t = t.to(torch.float64)
+    f0 = f(t[0], y0)
+    out = [y0]
+    if len(tape) == 0:
+        return torch.stack(out + [y0] * (len(t) - 1), dim=0)
+    dt0 = torch.tensor(float(tape[0][1]), dtype=torch.float64)
+    if first_attempt_accepted:
+        dt_init = _initial_step(f, t[0], y0, 4, rtol, atol, f0)
+        dt0 = dt0 + (dt_init - dt_init.detach())
+    if stats is not None and dt0.requires_grad:
+        dt0.retain_grad()  # after backward: stats["dt0"].grad is d loss / d dt_0
+        stats["dt0"] = dt0
+    shift = dt0 - dt0.detach()  # zero-valued carrier of d/d(dt_0) for every later step boundary
+    y, fy = y0, f0
+    j = 1
+    for n, (t_n, dt_n) in enumerate(tape):
+        if j >= len(t):
+            break
+        if n == 0:
+            t_lo, dt = t[0], dt0
+        else:
+            t_lo, dt = torch.tensor(float(t_n), dtype=torch.float64) + shift, torch.tensor(float(dt_n), dtype=torch.float64)
+        t_hi = t_lo + dt
+        y1, f1, _, k = _dp_attempt(f, y, fy, t_lo, dt, t_hi, tab)
+        if t[j] <= t_hi:
+            coef = _interp_fit(y, y1, k, dt, c_mid)
+            while j < len(t) and t[j] <= t_hi:
+                out.append(_interp_eval(coef, t_lo, t_hi, t[j]))
+                j += 1
+        y, fy = y1, f1
+    assert j == len(t), "tape ends before the last output time"
     return torch.stack(out, dim=0)
 
 

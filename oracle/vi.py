@@ -25,10 +25,15 @@ class DecoderOracle(nn.Module):
         self.t = torch.arange(0, t_max + step_size, step_size, dtype=torch.float32)  # model.py:1072
         self.output_function = nn.Sequential(nn.Linear(latent_dim, obs_dim, bias=True))  # created first, model.py:1097
         self.ode = RocheRHS(latent_dim, step_size, ablate=ablate) if roche else NeuralRHS(latent_dim, step_size)
+        #: tests may swap the solver call, e.g. for ``solvers.odeint_dopri5_replay`` along another run's step tape
+        self.solve = None
 
     def forward(self, init, a):
         self.ode.set_action(a)
-        h = odeint(self.ode, init, self.t, rtol=1e-7, atol=1e-8, method=self.method)
+        if self.solve is not None:
+            h = self.solve(self.ode, init, self.t)
+        else:
+            h = odeint(self.ode, init, self.t, rtol=1e-7, atol=1e-8, method=self.method)
         return self.output_function(h), h
 
 

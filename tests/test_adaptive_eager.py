@@ -54,11 +54,11 @@ def test_dose_jumps_tape_adjoint_equals_autograd_over_the_same_tape():
     """With dose jumps inside the window the controller sits at ratio ~ 1 and the accept / reject sequence is chaotic in
     the last bit of the error norm (it differs between two CPUs for the ORACLE alone; tests/test_hip_dopri5.py has the
     same finding for the HIP kernels), so the oracle pins the trajectory only to the solver tolerance here.  The adjoint
-    algebra is pinned exactly instead: the stepwise reverse sweep against one autograd graph over the same accepted tape.
-    Also quantified: torchdiffeq's graph (and the oracle's) differentiates the FIRST step size -- Hairer's h0 is a function
-    of y0 and f0 outside `no_grad` -- while every later one is a constant; with a jump in the window that moves all
-    later step boundaries relative to the jump, an artefact of 2-5 % of grad_y0 that neither this module nor the HIP
-    adjoint kernel reproduces."""
+    algebra is pinned exactly instead: the stepwise reverse sweep against one autograd graph over the same accepted tape
+    (first step size detached on both sides), and -- torchdiffeq's graph differentiates the FIRST step size, Hairer's h0
+    being a function of y0 and f0 outside `no_grad`, which with a jump in the window moves all later step boundaries
+    relative to the jump: 2-5 % of grad_y0 here -- the default path against the oracle's step algebra replayed along the
+    same tape with that term (oracle/solvers.py::odeint_dopri5_replay)."""
     import oracle.solvers as osol
     torch.manual_seed(0)
     D, B, T, step = 6, 5, 12, 0.125
@@ -67,7 +67,7 @@ def test_dose_jumps_tape_adjoint_equals_autograd_over_the_same_tape():
     y0 = (torch.rand(B, D) * 0.1).requires_grad_(True)
     t = torch.arange(T) * step
     cot = torch.randn(T, B, D)
-    h = ae.odeint_dopri5(f, y0, t, rtol=1e-6, atol=1e-8)
+    h = ae.odeint_dopri5(f, y0, t, rtol=1e-6, atol=1e-8, detach_first_step=True)
     steps = h.grad_fn.steps
     g = _grads(h, cot, y0, f)
     assert ae.last_stats["n_rejected"] > ae.last_stats["n_accepted"] > 20  # the regime described above
@@ -86,6 +86,21 @@ def test_dose_jumps_tape_adjoint_equals_autograd_over_the_same_tape():
         if b is None or float(b.abs().max()) == 0.0:
             continue
         assert float((a - b).norm() / b.norm()) <= 2e-5
+
+    # the reference's graph: first step size differentiated.  Same tape, the oracle's algebra with that term.
+    h_full = ae.odeint_dopri5(f, y0, t, rtol=1e-6, atol=1e-8)
+    first = h_full.grad_fn.first_accepted
+    g_full = _grads(h_full, cot, y0, f)
+    rs = {}
+    h_rep = osol.odeint_dopri5_replay(f, y0, t, 1e-6, 1e-8, [(s[0], s[1]) for s in steps], first, stats=rs)
+    g_rep = _grads(h_rep, cot, y0, f)
+    assert first and (h_full.detach() - h_rep.detach()).abs().max().item() <= 2e-6
+    assert abs(ae.last_stats["sigma"] - float(rs["dt0"].grad)) <= 2e-3 * abs(float(rs["dt0"].grad))
+    for a, b in zip(g_full, g_rep):
+        if b is None or float(b.abs().max()) == 0.0:
+            continue
+        assert float((a - b).norm() / b.norm()) <= 1e-4
+    assert float((g[0] - g_rep[0]).norm() / g_rep[0].norm()) >= 1e-3  # the term is material on this problem
 
     stats = {}
     h_o = osol.odeint(f, y0, t, rtol=1e-6, atol=1e-8, method="dopri5", stats=stats)

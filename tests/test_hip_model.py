@@ -38,13 +38,25 @@ def test_vi_loss_and_grads_match_cpu_oracle(method, obs, D):
     sol = synth.solver_inputs(B, T, D, seed=3)
     ob = synth.observation_inputs(B, T, obs, seed=3)
     data = {"measurements": ob["measurements"], "actions": sol["actions"], "masks": ob["masks"]}
-    loss = vi.loss({k: v.to(dev) for k, v in data.items()})
-    loss.backward()
+    from hode import adaptive
+    adaptive.keep_workspace = method == "dopri5"
+    try:
+        loss = vi.loss({k: v.to(dev) for k, v in data.items()})
+        loss.backward()
+        if method == "dopri5":
+            # drive the oracle's step algebra along the HIP run's own (t_n, dt_n) tape: accept / reject decisions that flip
+            # on the last bit of the error norm (tests/test_hip_dopri5.py) drop out and every gradient can be held tightly
+            from oracle.solvers import odeint_dopri5_replay
+            tape = adaptive.read_tape()
+            pairs, first = list(zip(tape["t"], tape["dt"])), bool(tape["init"]["first_accepted"])
+            dec_o.solve = lambda f, y0, t: odeint_dopri5_replay(f, y0, t, 1e-7, 1e-8, pairs, first)
+    finally:
+        adaptive.keep_workspace = False
     loss_o = ovi.vi_loss(enc_o, dec_o, data, elbo=False)
     loss_o.backward()
-    # dopri5: the two controllers' step sequences drift apart at the dose jumps (tests/test_hip_dopri5.py); the noise that
-    # puts on grad_z0 (~1e-2) is amplified by cancellation in the encoder's weight gradients
-    tol_h, tol_g = (3e-5, 2e-3) if method == "rk4" else (2e-4, 2e-2)
+    # dopri5: the derivative of Hairer's first step size (part of the reference's graph) is a cancellation-heavy fp32 sum:
+    # the oracle's own fp32 evaluation sits up to 7e-4 from the fp64 one (tests/test_hip_dopri5.py), hence 5e-3 here
+    tol_h, tol_g = (3e-5, 2e-3) if method == "rk4" else (3e-5, 5e-3)
     assert abs(loss.item() - loss_o.item()) <= 2e-4 * abs(loss_o.item())
     assert (vi.h_hat.detach().cpu() - odeint_h(dec_o, enc_o, data)).abs().max().item() <= tol_h * 10
     for (n, p), (_, po) in zip(list(enc.named_parameters()) + list(dec.named_parameters()),
@@ -54,15 +66,6 @@ def test_vi_loss_and_grads_match_cpu_oracle(method, obs, D):
             continue
         assert p.grad is not None, n
         if float(po.grad.abs().max()) < 1e-12:
-            continue
-        if method == "dopri5" and not n.startswith("output_function"):
-            # gradients that pass through the adaptive solve carry the step-sequence noise quantified in
-            # tests/test_hip_dopri5.py (grad_z0 ~1e-2); sums with heavy cancellation (LSTM weights, the scalar rate
-            # constants -- d/dkel flips between -0.28 and -0.72 with the step sequence) are noise dominated.  The
-            # adjoint algebra itself is pinned on the smooth problem there (5e-7); here: finite, and ml_net in range.
-            assert torch.isfinite(p.grad).all(), n
-            if "ml_net" in n:
-                assert _rel(p.grad, po.grad) <= 0.5, (n, _rel(p.grad, po.grad))
             continue
         assert _rel(p.grad, po.grad) <= tol_g, (n, _rel(p.grad, po.grad))
 
