@@ -6,7 +6,7 @@ through the C ABI declared in ``include/hode.h``.  There is no CPU or PyTorch fa
 calling it without the library or with CPU tensors raises.
 """
 
-from ._lib import HodeError, lib, library_path  # noqa: F401
+from ._lib import HodeConfigError, HodeError, lib, library_path  # noqa: F401
 from .solver import odeint, roche_solve  # noqa: F401
 
-__all__ = ["odeint", "roche_solve", "lib", "library_path", "HodeError"]
+__all__ = ["odeint", "roche_solve", "lib", "library_path", "HodeError", "HodeConfigError"]

@@ -20,8 +20,16 @@ FLAG_SKIP_FOLD, FLAG_OVERWRITE_GRADS, FLAG_TAPE, FLAG_DETACH_FIRST_STEP, FLAG_NO
 
 
 class HodeError(RuntimeError):
-    """Raised for every non-zero return of a libhode entry point (RuntimeError so that the
-    reference's ``except RuntimeError`` around ``model.loss`` keeps catching solver failures)."""
+    """NUMERICAL failure of a solve, reported by the kernels' status word: non-finite state, dt underflow, step bound
+    exceeded.  A RuntimeError so that the reference's ``except RuntimeError`` around ``model.loss``
+    (training_utils.py:43-47) keeps ending a diverged restart."""
+
+
+class HodeConfigError(Exception):
+    """Everything that is NOT the numerics' fault: libhode.so missing / stale / ABI mismatch, an argument error or
+    unsupported shape reported by an entry point (HODE_E_*), a HIP launch error, CPU tensors handed to the GPU-only
+    path.  Deliberately not a RuntimeError: the mirrored training loop must not mistake it for solver divergence,
+    print it, save the untrained model and carry on."""
 
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -123,13 +131,13 @@ def library_path() -> str:
 
 
 def lib():
-    """Load (once) and return the ctypes handle; raises HodeError if the library is absent or stale."""
+    """Load (once) and return the ctypes handle; raises HodeConfigError if the library is absent or stale."""
     global _lib
     if _lib is not None:
         return _lib
     path = library_path()
     if not os.path.exists(path):
-        raise HodeError(
+        raise HodeConfigError(
             "hode: %s not found -- build it with `python build_hip.py` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the solver path." % path
         )
@@ -139,7 +147,7 @@ def lib():
         fn.restype = restype
         fn.argtypes = list(argtypes)
     if handle.hode_version() != HODE_ABI_VERSION:
-        raise HodeError("hode: ABI version %d != expected %d" % (handle.hode_version(), HODE_ABI_VERSION))
+        raise HodeConfigError("hode: ABI version %d != expected %d" % (handle.hode_version(), HODE_ABI_VERSION))
     _lib = handle
     return _lib
 
@@ -147,7 +155,7 @@ def lib():
 def check(code: int, what: str):
     if code != 0:
         msg = lib().hode_last_error_string().decode("utf-8", "replace")
-        raise HodeError("%s failed (code %d): %s" % (what, code, msg))
+        raise HodeConfigError("%s failed (code %d): %s" % (what, code, msg))
 
 
 def new_solve_desc() -> SolveDesc:

@@ -28,7 +28,7 @@ def read_tape():
     back from the workspace at the offsets ``hode_dopri5_tape_offsets`` reports.  After the backward ``init["sigma"]`` is
     d loss / d dt_0."""
     if _last_ws is None:
-        raise L.HodeError("hode.adaptive.read_tape: no workspace kept (set keep_workspace = True before the solve)")
+        raise L.HodeConfigError("hode.adaptive.read_tape: no workspace kept (set keep_workspace = True before the solve)")
     ws, d, n_acc = _last_ws
     off = (C.c_size_t * 5)()
     L.check(L.lib().hode_dopri5_tape_offsets(d, off), "hode_dopri5_tape_offsets")

@@ -90,7 +90,7 @@ class _NeuralFixedGrid(torch.autograd.Function):
 def neural_solve(y0, w1, b1, w2, b2, t, dosage, dose_times, method="rk4", perturb=False):
     """h (T, B, D) for dy/dt = tanh(W2 tanh(W1 [y, Dose(t)] + b1) + b2); fixed-grid methods only."""
     if method not in L.METHODS:
-        raise L.HodeError("hode: the neural rhs is built for the fixed-grid methods (euler, midpoint, rk4); got %r" % (method,))
+        raise L.HodeConfigError("hode: the neural rhs is built for the fixed-grid methods (euler, midpoint, rk4); got %r" % (method,))
     if dose_times.dim() != 2:
         dose_times = dose_times.reshape(y0.shape[0], -1)
     return _NeuralFixedGrid.apply(y0, w1, b1, w2, b2, t, dosage, dose_times.to(torch.float32), L.METHODS[method], bool(perturb))

@@ -48,7 +48,9 @@ class GradBucket:
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         first = self.params[0]
-        self.flat = torch.zeros(self.numel, device=first.device, dtype=torch.float32)
+        # one extra slot behind the gradients: the "this rank's step failed" flag of the training loop rides along
+        self._buf = torch.zeros(self.numel + 1, device=first.device, dtype=torch.float32)
+        self.flat = self._buf[:self.numel]
 
     def _gather(self, weight=1.0):
         off = 0
@@ -73,13 +75,19 @@ class GradBucket:
                 p.grad.copy_(g)
             off += n
 
-    def all_reduce_mean(self, weight=1.0):
+    def all_reduce_mean(self, weight=1.0, failed=None):
+        """Average the gradients over the ranks in place.  With ``failed`` given (a bool: did THIS rank's step fail) the
+        flag travels in the same collective and the call returns whether ANY rank failed -- one host read-back, so that
+        all ranks leave the training loop in the same iteration; otherwise it returns the flat gradient view."""
         self._gather(weight)
+        self._buf[self.numel] = 1.0 if failed else 0.0
         if is_distributed():
             if dist.get_backend() == "gloo":  # gloo has no AVG
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                self.flat.div_(dist.get_world_size())
+                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
+                self._buf.div_(dist.get_world_size())
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+                dist.all_reduce(self._buf, op=dist.ReduceOp.AVG)
         self._scatter()
-        return self.flat
+        if failed is None:
+            return self.flat
+        return bool(self._buf[self.numel].item() > 0.0)

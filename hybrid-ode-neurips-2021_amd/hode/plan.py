@@ -17,7 +17,7 @@ class RocheRKPlan:
                  lanes_per_patient=0, need_theta_grad=True, tape=True):
         for x in (y0, theta, t, dosage, dose_times):
             if not x.is_cuda:
-                raise L.HodeError("hode: RocheRKPlan needs HIP-device tensors (no CPU fallback)")
+                raise L.HodeConfigError("hode: RocheRKPlan needs HIP-device tensors (no CPU fallback)")
         self.lib = L.lib()
         self.dev = y0.device
         B, D = y0.shape

@@ -99,5 +99,5 @@ class _RealFixedGrid(torch.autograd.Function):
 def real_solve(y0, theta, wflat, t, act, hidden, method="midpoint", perturb=True):
     """h (T, B, D).  ``theta`` = (k_immunity, kel, kel2); ``wflat`` = all weights in creation order; ``act`` (Ta, B) doses."""
     if method not in L.METHODS:
-        raise L.HodeError("hode: the real-data rhs is built for the fixed-grid methods (euler, midpoint, rk4); got %r" % (method,))
+        raise L.HodeConfigError("hode: the real-data rhs is built for the fixed-grid methods (euler, midpoint, rk4); got %r" % (method,))
     return _RealFixedGrid.apply(y0, theta, wflat, t, act, L.METHODS[method], bool(perturb), int(hidden))

@@ -17,7 +17,7 @@ from . import _lib as L
 def _require_gpu(*tensors):
     for x in tensors:
         if x is not None and not x.is_cuda:
-            raise L.HodeError(
+            raise L.HodeConfigError(
                 "hode: the solver path runs only on a HIP device (got a %s tensor); there is no CPU fallback" % x.device
             )
 
@@ -109,7 +109,7 @@ class _RocheFixedGrid(torch.autograd.Function):
         nbytes = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
         ws = ctx.tape_ws if ctx.tape_ws is not None else torch.empty(max(nbytes, 4), device=h.device, dtype=torch.uint8)
         if ws.numel() < nbytes:
-            raise L.HodeError("hode: tape buffer of the forward (%d B) is smaller than the backward needs (%d B)" % (ws.numel(), nbytes))
+            raise L.HodeConfigError("hode: tape buffer of the forward (%d B) is smaller than the backward needs (%d B)" % (ws.numel(), nbytes))
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         with torch.cuda.device(h.device):
             L.check(lib.hode_rk_bwd(d, _stream()), "hode_rk_bwd")
@@ -135,7 +135,7 @@ def odeint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=None):
     """Same signature as ``torchdiffeq.odeint``; ``func`` is an rhs module of this package (has ``hode_solve``)."""
     solve = getattr(func, "hode_solve", None)
     if solve is None:
-        raise L.HodeError(
+        raise L.HodeConfigError(
             "hode.odeint: %s is not a hode rhs module (no hode_solve); arbitrary Python rhs callables are outside "
             "the accelerated path" % type(func).__name__
         )

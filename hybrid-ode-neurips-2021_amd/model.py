@@ -243,7 +243,7 @@ def _eager_dopri5(ode, y0, t, rtol, atol, options):
     accepted-step tape) -- said once per rhs class, never silently, and never on the CPU."""
     from hode import adaptive_eager
     if not y0.is_cuda:
-        raise hode.HodeError("hode: %s needs its tensors on a HIP device (there is no CPU path)" % type(ode).__name__)
+        raise hode.HodeConfigError("hode: %s needs its tensors on a HIP device (there is no CPU path)" % type(ode).__name__)
     name = type(ode).__name__
     if name not in _EAGER_DOPRI5_ANNOUNCED:
         _EAGER_DOPRI5_ANNOUNCED.add(name)
@@ -319,7 +319,7 @@ class EncoderLSTMReal(nn.Module, GaussianReparam):
 
     def forward(self, x, a, m):
         if self.output_all:
-            raise hode.HodeError("EncoderLSTMReal(output_all=True) is outside the accelerated path")
+            raise hode.HodeConfigError("EncoderLSTMReal(output_all=True) is outside the accelerated path")
         if self.reverse:
             x, a, m = torch.flip(x, [0]), torch.flip(a, [0]), torch.flip(m, [0])
         T, B = m.shape[0], m.shape[1]
@@ -394,7 +394,7 @@ class RocheODEReal(nn.Module):
         if method == "dopri5":
             # DecoderReal hands dopri5 a `step_t` grid (model.py:826: steps are cut at the hourly dose switches); that
             # option's semantics are restated neither by the oracle nor by hode.adaptive_eager.  real.sh:15 uses midpoint.
-            raise hode.HodeError("hode: RocheODEReal is built for the fixed-grid methods (euler, midpoint, rk4); "
+            raise hode.HodeConfigError("hode: RocheODEReal is built for the fixed-grid methods (euler, midpoint, rk4); "
                                  "dopri5 with options['step_t'] is not supported")
         from hode import substep
         step_size = options.pop("step_size", None)
@@ -453,7 +453,7 @@ class DecoderReal(nn.Module):
         self.output_function = nn.Sequential(nn.Linear(latent_dim, latent_dim + 1, bias=True), nn.ELU(),
                                              nn.Linear(latent_dim + 1, obs_dim, bias=True)).to(self.device)
         if ode_type in ("neural", "2nd"):
-            raise hode.HodeError("DecoderReal(ode_type=%r): NeuralODEReal baselines are outside the accelerated path" % ode_type)
+            raise hode.HodeConfigError("DecoderReal(ode_type=%r): NeuralODEReal baselines are outside the accelerated path" % ode_type)
         self.ode = RocheODEReal(latent_dim, action_dim, static_dim, hidden_dim, t_max, step_size, self.device)
         self.t = torch.arange(t0 - 1, t_max, step_size, device=self.device, dtype=dtype)
         self.options = {"step_t": self.t, "step_size": ode_step_size, "perturb": True}
@@ -465,7 +465,7 @@ class DecoderReal(nn.Module):
     def forward(self, init, a, s):
         self.ode.set_action_static(a, s)
         if init.dim() != 2:
-            raise hode.HodeError("DecoderReal: per-step initial states (3-D init) are outside the accelerated path")
+            raise hode.HodeConfigError("DecoderReal: per-step initial states (3-D init) are outside the accelerated path")
         h = self._odeint(self.ode, init, self.t, method=self.method, options=dict(self.options), rtol=self.rtol, atol=self.atol)
         if h.is_cuda and h.shape[0] * h.shape[1] >= 65536:
             return _tall_mlp(self.output_function, h)[1:], h

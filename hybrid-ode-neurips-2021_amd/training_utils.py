@@ -1,18 +1,48 @@
 """Training loop with the reference's control flow (``training_utils.py:8-97``): fixed-chunk or random minibatches,
 validation every ``test_freq`` iterations, best-on-disk checkpoint, early stopping, reload of the best checkpoint.
 
-Added for multi-GPU: when ``torch.distributed`` is initialised each rank trains on its own shard of every minibatch
-and the flat gradient bucket is averaged with one RCCL all-reduce per step (``hode.parallel.GradBucket``).
+Added for multi-GPU: when ``torch.distributed`` is initialised every rank draws the SAME minibatch (the
+generators are seeded identically), keeps its contiguous shard of the patients (``hode.parallel.shard_batch``) and the
+flat gradient bucket is averaged with one RCCL all-reduce per step (``hode.parallel.GradBucket``).  Every decision that
+ends or redirects the loop is taken on all-reduced quantities, so the ranks leave it together: a solver failure on one
+rank's shard travels in the bucket's flag slot and stops every rank before the optimiser step; the validation total is
+the mean of the per-rank totals (losses are normalised per local batch, reference model.py:1179,1188); rank 0 alone
+writes checkpoints and the others wait for it before reading.
 """
 import time
 
 import torch
+import torch.distributed as dist
 
-from hode.parallel import GradBucket, is_distributed, rank0_print
+from hode.parallel import GradBucket, is_distributed, rank0_print, shard_batch
 
 
 def _trainable(optimizer):
     return [p for g in optimizer.param_groups for p in g["params"]]
+
+
+def _local(data):
+    return shard_batch(data) if is_distributed() else data
+
+
+def _validation_total(model, data_generator, batch_size):
+    """Sum of the validation losses over the fold's chunks; a failing chunk counts 1e9 and ends the pass
+    (reference :57-66).  Distributed: mean over ranks, and one rank's failure is every rank's."""
+    total, failed = 0.0, 0.0
+    for chunk in range(data_generator.val_size // batch_size):
+        data = _local(data_generator.get_split("val", batch_size, chunk))
+        try:
+            total += model.loss(data).item()
+        except RuntimeError as e:
+            failed = 1.0
+            print(e)
+            break
+    if is_distributed():
+        dev = next(model.encoder.parameters()).device
+        buf = torch.tensor([total, failed], dtype=torch.float64, device=dev)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        total, failed = float(buf[0]) / dist.get_world_size(), float(buf[1])
+    return total + (1e9 if failed else 0.0)
 
 
 def variational_training_loop(niters, data_generator, model, batch_size, optimizer, test_freq, best_on_disk=1e9,
@@ -21,7 +51,9 @@ def variational_training_loop(niters, data_generator, model, batch_size, optimiz
     stale = 0
     fold_size = data_generator.train_size if train_fold == "train" else data_generator.val_size
     train_chunk = fold_size // batch_size
-    bucket = GradBucket(_trainable(optimizer)) if is_distributed() else None
+    distributed = is_distributed()
+    bucket = GradBucket(_trainable(optimizer)) if distributed else None
+    rank = dist.get_rank() if distributed else 0
 
     start = time.time()
     for itr in range(1, niters + 1):
@@ -29,28 +61,32 @@ def variational_training_loop(niters, data_generator, model, batch_size, optimiz
             data = data_generator.get_mini_batch(train_fold, batch_size)
         else:
             data = data_generator.get_split(train_fold, batch_size, itr % train_chunk)
+        data = _local(data)
         optimizer.zero_grad()
+        failure = None
         try:
             loss = model.loss(data)
         except RuntimeError as e:  # solver blow-up (non-finite state, dt underflow) ends this restart
-            rank0_print(e)
-            break
-        loss.backward()
-        if bucket is not None:
-            bucket.all_reduce_mean()
+            failure = e
+        if not distributed:
+            if failure is not None:
+                print(failure)
+                break
+            loss.backward()
+        else:
+            # the exchange is collective: a rank whose shard failed still takes part, with zero gradients and its flag up
+            if failure is None:
+                loss.backward()
+            else:
+                print(failure)
+                optimizer.zero_grad()
+            if bucket.all_reduce_mean(failed=failure is not None):
+                break
         optimizer.step()
 
         if itr % test_freq == 0:
             with torch.no_grad():
-                total = 0
-                for chunk in range(data_generator.val_size // batch_size):
-                    data = data_generator.get_split("val", batch_size, chunk)
-                    try:
-                        total += model.loss(data).item()
-                    except RuntimeError as e:
-                        total += 1e9
-                        rank0_print(e)
-                        break
+                total = _validation_total(model, data_generator, batch_size)
                 rank0_print("Iter {:04d} | Total Loss {:.6f} | Train Loss {:.6f}".format(itr, total, loss.item()))
                 if total < best_loss:
                     best_loss, stale = total, 0
@@ -58,15 +94,21 @@ def variational_training_loop(niters, data_generator, model, batch_size, optimiz
                     stale += 1
                 if total < best_on_disk:
                     best_on_disk = total
-                    model.save(path, itr, best_on_disk)
+                    if rank == 0:
+                        model.save(path, itr, best_on_disk)
         if stale >= early_stop:
             break
     end = time.time()
 
+    if distributed:
+        dist.barrier()  # rank 0's last checkpoint is on disk before anyone reads it
     try:
         best = torch.load(path + model.model_name)
     except FileNotFoundError:
-        model.save(path, 0, best_on_disk)
+        if rank == 0:
+            model.save(path, 0, best_on_disk)
+        if distributed:
+            dist.barrier()
         best = torch.load(path + model.model_name)
     model.encoder.load_state_dict(best["encoder_state_dict"])
     model.decoder.load_state_dict(best["decoder_state_dict"])

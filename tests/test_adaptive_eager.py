@@ -137,5 +137,6 @@ def test_failures_are_runtime_errors():
 
 def test_mirror_refuses_cpu_tensors_for_the_eager_path():
     dec = model.RocheExpertDecoder(6, 6, 1, 1.0, 0.125, roche=False, method="dopri5", device=torch.device("cpu"))
-    with pytest.raises(RuntimeError, match="HIP device"):
+    import hode
+    with pytest.raises(hode.HodeConfigError, match="HIP device"):
         dec(torch.rand(3, 6) * 0.1, _actions(9, 3))

@@ -109,5 +109,5 @@ def test_bootstrap_rmse_is_the_reference_estimator():
 def test_product_crps_refuses_cpu_tensors():
     import hode
     from hode import crps
-    with pytest.raises(hode.HodeError):
+    with pytest.raises(hode.HodeConfigError):
         crps.ensemble_crps(torch.zeros(1, 4, 3), torch.zeros(1, 2, 3), 2)

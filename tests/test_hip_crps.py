@@ -64,9 +64,9 @@ def test_argument_errors():
     from hode.crps import ensemble_crps
     with pytest.raises(ValueError):
         ensemble_crps(torch.zeros(1, 7, 4, device=dev), torch.zeros(1, 2, 4, device=dev), 3)
-    with pytest.raises(hode.HodeError):
+    with pytest.raises(hode.HodeConfigError):
         ensemble_crps(torch.zeros(1, 2 * 129, 4, device=dev), torch.zeros(1, 2, 4, device=dev), 129)
-    with pytest.raises(hode.HodeError):  # identity readout asks for more components than a member vector has
+    with pytest.raises(hode.HodeConfigError):  # identity readout asks for more components than a member vector has
         ensemble_crps(torch.zeros(1, 4, 3, device=dev), torch.zeros(1, 2, 5, device=dev), 2)
 
 

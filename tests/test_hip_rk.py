@@ -198,9 +198,9 @@ def test_errors_are_loud():
     inp, f = _case(8, 6, 12, seed=1)
     dosage, times = dose_schedule(inp["actions"], f.step_size)
     theta = torch.tensor(THETA_DEFAULT + (0.0,) * 3)
-    with pytest.raises(RuntimeError):  # CPU tensors: no fallback
+    with pytest.raises(hode.HodeConfigError):  # CPU tensors: no fallback
         roche_solve(inp["z0"], theta, f.ml_net[0].weight, f.ml_net[0].bias, inp["t"], dosage, times)
-    with pytest.raises(hode.HodeError):  # unsupported latent dim
+    with pytest.raises(hode.HodeConfigError):  # unsupported latent dim: a configuration error, not divergence
         roche_solve(torch.zeros(4, 7, device=dev), theta.to(dev), torch.zeros(3, 7, device=dev), torch.zeros(3, device=dev),
                     inp["t"].to(dev), torch.zeros(4, device=dev), torch.zeros(4, 1, device=dev))
 

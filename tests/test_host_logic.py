@@ -72,7 +72,8 @@ def test_rhs_as_torch_function_matches_reference_golden(golden_dir):
 
 def test_product_decoder_refuses_cpu_and_missing_action():
     dec = model.RocheExpertDecoder(10, 8, 1, 1.0, 0.125, method="rk4", device=CPU)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    import hode
+    with pytest.raises(hode.HodeConfigError, match="no CPU fallback"):
         dec(torch.rand(3, 8), torch.zeros(9, 3, 1))
     dec = model.RocheExpertDecoder(10, 8, 1, 1.0, 0.125, method="rk4", device=CPU)
     with pytest.raises(RuntimeError, match="set_action"):
@@ -187,7 +188,8 @@ def test_neural_and_real_mirrors_surface():
     assert dr.ode.flat_weights().numel() == 9 * 43 + 2 + 3 * 16 * 16
     enc = model.EncoderLSTMReal(37, 44, 20, output_all=False, reverse=False, device=CPU)
     assert enc.model_name == "LSTMReal" and list(enc.state_dict())[:4] == ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0"]
-    with pytest.raises(RuntimeError):
+    import hode
+    with pytest.raises(hode.HodeConfigError):
         model.DecoderReal(24, 20, 1, 11, 43, 40, 1, ode_type="neural", device=CPU)
 
 
@@ -243,3 +245,43 @@ def test_substep_grid_and_output_reads_equal_the_oracle(step_size):
     g_ref, = torch.autograd.grad(ref.sum(), y0)
     g_got, = torch.autograd.grad(got.sum(), y0)
     assert torch.allclose(g_ref, g_got, rtol=1e-6, atol=1e-7)
+
+
+def test_training_loop_lets_configuration_errors_through(tmp_path):
+    """The mirrored loop catches RuntimeError around model.loss like the reference (solver divergence ends a restart);
+    a missing / stale library, an unsupported shape or CPU tensors are HodeConfigError and must surface instead of
+    being printed and followed by a checkpoint of the untrained model."""
+    import hode
+    import training_utils
+
+    class _Gen:
+        train_size = val_size = 4
+
+        def get_mini_batch(self, fold, n):
+            return {"measurements": torch.zeros(2, n, 3)}
+
+        get_split = get_mini_batch
+
+    class _Model:
+        model_name = "m"
+
+        def __init__(self, exc):
+            self.exc, self.saved = exc, 0
+            self.encoder = self.decoder = torch.nn.Linear(1, 1)
+
+        def loss(self, data):
+            raise self.exc
+
+        def save(self, path, itr, best):
+            self.saved += 1
+            torch.save({"encoder_state_dict": self.encoder.state_dict(), "decoder_state_dict": self.decoder.state_dict(),
+                        "best_loss": best}, path + self.model_name)
+
+    opt = torch.optim.SGD(torch.nn.Linear(1, 1).parameters(), lr=0.1)
+    m = _Model(hode.HodeConfigError("hode: libhode.so not found"))
+    with pytest.raises(hode.HodeConfigError):
+        training_utils.variational_training_loop(3, _Gen(), m, 4, opt, 1, path=str(tmp_path) + "/")
+    assert m.saved == 0
+    m = _Model(hode.HodeError("hode dopri5: underflow in dt"))  # numerical failure: handled like the reference does
+    training_utils.variational_training_loop(3, _Gen(), m, 4, opt, 1, path=str(tmp_path) + "/")
+    assert m.saved == 1

@@ -81,3 +81,86 @@ def test_shard_bounds_cover_ragged_batches():
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
     d = {"x": torch.arange(30).reshape(3, 10, 1)}
     assert shard_batch(d, 1, 3)["x"].shape == (3, 3, 1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# variational_training_loop itself at world size 2: shards, stop flag, rank-0 checkpoint
+
+class _Folds:
+    """Reference-style data generator (dataloader.py:322-341 signatures) over one seeded batch."""
+
+    def __init__(self, B=8):
+        self.data = _data(B=B)
+        self.data["latents"] = torch.zeros(self.data["measurements"].shape[0], B, 8)
+        self.train_size = self.val_size = B
+        self.expert_dim = 4
+
+    def get_split(self, fold, batch_size, chunk=0):
+        return {k: v[:, chunk * batch_size:(chunk + 1) * batch_size] for k, v in self.data.items()}
+
+    def get_mini_batch(self, fold, batch_size):
+        return self.get_split(fold, batch_size, 0)
+
+
+def _train(vi, enc, dec, path, fail_at=None):
+    import training_utils
+    params = list(enc.parameters()) + list(dec.output_function.parameters()) + list(dec.ode.ml_net.parameters())
+    opt = torch.optim.SGD(params, lr=1e-3)
+    calls = {"n": 0}
+    inner = vi.loss
+
+    def loss(data):
+        if data["measurements"].requires_grad or torch.is_grad_enabled():
+            calls["n"] += 1
+            if fail_at is not None and calls["n"] == fail_at:
+                raise RuntimeError("injected solver failure")
+        return inner(data)
+
+    vi.loss = loss
+    steps = {"n": 0}
+    inner_step = opt.step
+
+    def step(*a, **k):
+        steps["n"] += 1
+        return inner_step(*a, **k)
+
+    opt.step = step
+    out = training_utils.variational_training_loop(6, _Folds(), vi, 8, opt, 2, path=path, shuffle=False)
+    return out, steps["n"], params
+
+
+def _loop_worker(rank, world, port, out_dir, fail_rank):
+    for p in (ROOT, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vi, enc, dec = _build()
+    (_, best, _), n_steps, params = _train(vi, enc, dec, out_dir + "/ckpt_", fail_at=3 if rank == fail_rank else None)
+    torch.save({"steps": n_steps, "best": best, "flat": torch.cat([p.detach().reshape(-1) for p in params])},
+               os.path.join(out_dir, "loop_r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loop_two_ranks_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path), -1), nprocs=2, join=True)
+    r0, r1 = torch.load(str(tmp_path / "loop_r0.pt")), torch.load(str(tmp_path / "loop_r1.pt"))
+    assert r0["steps"] == r1["steps"] == 6
+    assert torch.equal(r0["flat"], r1["flat"]) and r0["best"] == r1["best"]  # same averaged gradients, same checkpoint
+    vi, enc, dec = _build()
+    os.makedirs(str(tmp_path / "single"))
+    (_, best, _), n_steps, params = _train(vi, enc, dec, str(tmp_path / "single") + "/ckpt_")
+    assert n_steps == 6
+    torch.testing.assert_close(r0["flat"], torch.cat([p.detach().reshape(-1) for p in params]), rtol=2e-4, atol=1e-6)
+    assert abs(best - r0["best"]) <= 2e-4 * abs(best)
+
+
+def test_training_loop_failure_on_one_rank_stops_every_rank(tmp_path):
+    """Rank 1's third model.loss raises (a solver blow-up on its shard): both ranks must leave the loop in that
+    iteration -- no rank left waiting in the gradient all-reduce -- with two optimiser steps done and the same weights."""
+    port = _free_port()
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path), 1), nprocs=2, join=True)
+    r0, r1 = torch.load(str(tmp_path / "loop_r0.pt")), torch.load(str(tmp_path / "loop_r1.pt"))
+    assert r0["steps"] == r1["steps"] == 2
+    assert torch.equal(r0["flat"], r1["flat"])
