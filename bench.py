@@ -6,14 +6,27 @@ Workload (BASELINE.json configs[1]): dim=12 synthetic, 10 000 patients PER GPU, 
 rank's batch (+ one RCCL all-reduce of the parameter-gradient bucket when N>1).  Inputs are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--no-graph]
+Besides the headline the default run also measures (same shape, same patients):
+  * "parity"             -- the shipped kernels (split layout + stage tape + hipGraph) against the CPU oracle on ALL
+                            10 000 patients of this very run: trajectory MSE / max-abs, gradient rel-L2
+  * "cpu_baseline"       -- that oracle, timed: 3 warm-up + 5 repetitions, median, all host cores of the share
+  * "full_training_step" -- encoder (MFMA LSTM) + solver + readout + loss, forward + backward, with its own roofline
+                            (MFMA fraction), cpu_baseline and parity (oracle pipeline on a sample)
+  * "dopri5_step"        -- BASELINE config 3 per GPU: adaptive solve + tape adjoint, with roofline (per attempt),
+                            cpu_baseline and parity (the oracle's step algebra replayed along the run's own tape)
+`--headline-only` skips the two extra blocks, `--no-cpu` every CPU leg.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` without a launcher starts that command itself (before anything touches the GPU).
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -21,9 +34,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
 
-import torch  # noqa: E402
+N_PER_GPU, T, D, OBS = 10000, 100, 12, 80
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32: exact fp32 in / fp32 accumulate (same guide); no TF32 on gfx950
+LSTM_MFLOP_PER_TRAJ = 92.5    # 2 T (I+H) 4H = 30.8 Mflop forward at T=100, I=81, H=160, x3 for fwd+bwd
 
-N_PER_GPU, T, D = 10000, 100, 12
+
 def host_cores():
     """CPU cores this process may actually use: affinity mask, capped by the cgroup quota (the GPU box gives a
     16-core share of a much larger host; sizing thread pools by os.cpu_count() there oversubscribes badly)."""
@@ -48,68 +64,114 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh ranks through torch.distributed.run as a
+    CHILD process -- this parent has not touched the GPU -- relay its stdout (the one JSON line) and exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    sys.stdout.write(r.stdout.decode())
+    sys.stdout.flush()
+    sys.exit(r.returncode)
 
 
-def build_plan(dev, rank, lanes=0, need_theta=True, tape=True):
+def _rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def solver_problem(rank):
+    import torch
     from hode import synth
-    from hode.plan import RocheRKPlan
-    from hode.solver import pack_theta
     inp = synth.solver_inputs(N_PER_GPU, T, D, seed=synth.SEED + rank)
     w, b = synth.default_ml_weights(D)
     theta = torch.tensor((2.0, 2.0) + (1.0,) * 11 + (0.0,) * 3)  # RochConfig defaults (sim_config.py:4-18)
     chan = inp["actions"][..., 0]
     dosage = chan.max(dim=0)[0]
     times = (torch.nonzero((chan != 0).t())[:, 1].reshape(N_PER_GPU, -1) * synth.STEP).float()
-    plan = RocheRKPlan(inp["z0"].to(dev), theta.to(dev), w.to(dev), b.to(dev), inp["t"].to(dev), dosage.to(dev),
-                       times.to(dev), method="rk4", lanes_per_patient=lanes, need_theta_grad=need_theta, tape=tape)
-    gen = torch.Generator().manual_seed(99 + rank)
-    plan.grad_h.copy_(torch.randn(T, N_PER_GPU, D, generator=gen))  # synthetic cotangent (what the readout+loss would send)
-    return plan, inp, (w, b)
+    cot = torch.randn(T, N_PER_GPU, D, generator=torch.Generator().manual_seed(99 + rank))  # what readout+loss would send
+    return {"inp": inp, "w": w, "b": b, "theta": theta, "dosage": dosage, "times": times, "cot": cot}
 
 
-def cpu_baseline(inp, wb, n_sample=2000, reps=3):
-    """The CPU oracle (op-for-op PyTorch eager restatement of the reference path, autograd backward) on a bounded
-    sample of the same workload: first `n_sample` patients, all host threads."""
-    from oracle.rhs import RocheRHS
-    from oracle.solvers import odeint
+def build_plan(dev, prob, lanes=0, need_theta=True, tape=True):
+    from hode.plan import RocheRKPlan
+    plan = RocheRKPlan(prob["inp"]["z0"].to(dev), prob["theta"].to(dev), prob["w"].to(dev), prob["b"].to(dev),
+                       prob["inp"]["t"].to(dev), prob["dosage"].to(dev), prob["times"].to(dev), method="rk4",
+                       lanes_per_patient=lanes, need_theta_grad=need_theta, tape=tape)
+    plan.grad_h.copy_(prob["cot"])
+    return plan
+
+
+def oracle_rhs(prob):
+    import torch
     from hode import synth
-    torch.set_num_threads(host_cores())
+    from oracle.rhs import RocheRHS
     f = RocheRHS(D, synth.STEP)
     with torch.no_grad():
-        f.ml_net[0].weight.copy_(wb[0])
-        f.ml_net[0].bias.copy_(wb[1])
-    a = inp["actions"][:, :n_sample]
-    z0 = inp["z0"][:n_sample]
-    cot = torch.randn(T, n_sample, D, generator=torch.Generator().manual_seed(99))
-    times = []
-    dt = 0.0
-    for i in range(reps + 1):
-        if i == 1 and dt > 15.0:  # bounded: keep the whole CPU leg to tens of seconds
-            reps = 1
-        if i > reps:
-            break
+        f.ml_net[0].weight.copy_(prob["w"])
+        f.ml_net[0].bias.copy_(prob["b"])
+    return f
+
+
+def cpu_baseline_and_parity(prob, gpu, warm=3, reps=5):
+    """The CPU oracle (op-for-op PyTorch eager restatement of the reference path, autograd backward) on the SAME
+    10 000 patients, the same cotangent: timed per SURVEY.md 8d (3 warm-up + 5 repetitions, median; the batch is cut
+    to 2 000 only if one repetition exceeds 60 s), and its outputs compared with what the GPU run left in HBM."""
+    import torch
+    from oracle.rhs import THETA_NAMES
+    from oracle.solvers import odeint
+    torch.set_num_threads(host_cores())
+    f = oracle_rhs(prob)
+    n = N_PER_GPU
+    times, first = [], None
+    i = 0
+    while i < warm + reps:
+        a, z0, cot = prob["inp"]["actions"][:, :n], prob["inp"]["z0"][:n], prob["cot"][:, :n]
         t0 = time.perf_counter()
         f.set_action(a)
         y0 = z0.clone().requires_grad_(True)
         f.zero_grad()
-        h = odeint(f, y0, inp["t"], method="rk4")
+        h = odeint(f, y0, prob["inp"]["t"], method="rk4")
         (h * cot).sum().backward()
         dt = time.perf_counter() - t0
-        log("cpu_baseline rep %d: %.2f s (%d threads)" % (i, dt, torch.get_num_threads()))
-        if i > 0:
+        log("cpu_baseline rep %d: %.2f s (%d patients, %d threads)" % (i, dt, n, torch.get_num_threads()))
+        if first is None and n == N_PER_GPU:
+            first = {"h": h.detach(), "gy0": y0.grad.clone(), "gw": f.ml_net[0].weight.grad.clone(),
+                     "gb": f.ml_net[0].bias.grad.clone(), "gth": torch.stack([getattr(f, k).grad for k in THETA_NAMES])}
+        if i == 0 and dt > 60.0 and n == N_PER_GPU:
+            n = 2000  # SURVEY 8d: reduce only past 60 s per repetition, and say so
+            continue
+        if i >= warm:
             times.append(dt)
+        i += 1
     med = statistics.median(times)
-    return {"value": n_sample / med, "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "first %d of %d patients, T=%d, D=%d, rk4, fwd+autograd bwd, 1 warm-up + %d reps (median %.3f s)"
-                      % (n_sample, N_PER_GPU, T, D, reps, med)}
+    base = {"value": n / med, "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%s %d patients, T=%d, D=%d, rk4, fwd + autograd bwd, %d warm-up + %d reps (median %.3f s)"
+                      % ("all" if n == N_PER_GPU else "first", n, T, D, warm, reps, med)}
+    par = None
+    if first is not None:
+        hg = gpu["h"].cpu()
+        err = (hg - first["h"]).double()
+        par = {"vs": "CPU oracle, all %d patients of this run, shipped kernels (%s)" % (N_PER_GPU, gpu["what"]),
+               "mse": float((err ** 2).mean()), "max_abs": float(err.abs().max()), "max_abs_h": float(first["h"].abs().max()),
+               "grad_y0_rel": _rel(gpu["gy0"], first["gy0"]), "grad_w_rel": _rel(gpu["gw"], first["gw"]),
+               "grad_b_rel": _rel(gpu["gb"], first["gb"]), "grad_theta_rel": _rel(gpu["gth"][:13], first["gth"]),
+               "tolerance": {"mse": 1e-5, "grad_rel": 1e-3}}
+        par["ok"] = bool(par["mse"] <= 1e-5 and max(par["grad_y0_rel"], par["grad_w_rel"], par["grad_b_rel"]) <= 1e-3)
+    return base, par
 
 
 def pmc_traffic(tape=True):
     """HBM bytes per launch of the dominant (backward) kernel from the committed rocprofv3 --pmc passes
-    (profiles/*_pmc_summary.json, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); None if absent.
-    The tape variant of the kernel (template arguments end in `true, true>`) reads the forward's stage tape on top of
-    the algorithmic bytes; the newest summary that holds the variant being timed wins."""
+    (profiles/*_pmc_summary.json, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); None if absent.  The counters
+    cannot be collected from inside this process, so this is the newest COMMITTED profile of the kernel variant being
+    timed (the JSON line says so in `traffic_source`)."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
@@ -118,6 +180,8 @@ def pmc_traffic(tape=True):
         except (OSError, ValueError):
             continue
         for k, v in d.items():
+            if not isinstance(v, dict):
+                continue
             if ("split_bwd_kernel<12" in k or "rk_bwd_kernel<12" in k) and "hbm_bytes_per_launch" in v:
                 if best is not None and "split" in best.get("kernel", "") and "split" not in k:
                     continue
@@ -125,61 +189,137 @@ def pmc_traffic(tape=True):
                     continue
                 if "split" in k and k.count(",") < 4 and tape:
                     continue
-                best = {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "kernel": k}
+                best = {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "kernel": k,
+                        "valu_active_frac": v.get("valu_active_frac")}
     return best
 
 
-def full_step_ms(dev, iters=5):
-    """Extra (not the headline): one full training step of the mirror model at the same shape -- MFMA LSTM encoder
-    (obs 80 -> H 160), HIP solver, readout, masked SSE + MC-KL, backward through everything."""
+# ---------------------------------------------------------------------------------------------------------------------
+# extra block 1: full training step
+
+def full_training_step(dev, iters=5, cpu=True, n_cpu=1000):
+    """One full training step of the mirror model at the bench shape -- MFMA LSTM encoder (obs 80 -> H 160), HIP solver,
+    fused readout + masked SSE, MC-KL, backward through everything -- plus the encoder alone (forward + BPTT + weight
+    gradients) for the MFMA roofline.  Returns the result block and a closure that adds the CPU legs (the oracle
+    pipeline on the first `n_cpu` patients as baseline and checker): every GPU measurement of the run is taken before
+    the first CPU leg, because the card clocks down while the host computes for tens of seconds."""
+    import torch
     import model
     from hode import synth
-    obs = 80
     torch.manual_seed(synth.SEED)
-    enc = model.EncoderLSTM(obs + 1, obs * 2, D, device=dev)
-    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * synth.STEP, synth.STEP, method="rk4", device=dev)
+    enc = model.EncoderLSTM(OBS + 1, OBS * 2, D, device=dev)
+    dec = model.RocheExpertDecoder(OBS, D, 1, (T - 1) * synth.STEP, synth.STEP, method="rk4", device=dev)
     vi = model.VariationalInference(enc, dec, prior_log_pdf=model.ExponentialPrior.log_density)
     sol = synth.solver_inputs(N_PER_GPU, T, D)
-    ob = synth.observation_inputs(N_PER_GPU, T, obs)
-    data = {k: v.to(dev) for k, v in {"measurements": ob["measurements"], "actions": sol["actions"], "masks": ob["masks"]}.items()}
+    ob = synth.observation_inputs(N_PER_GPU, T, OBS)
+    host = {"measurements": ob["measurements"], "actions": sol["actions"], "masks": ob["masks"]}
+    data = {k: v.to(dev) for k, v in host.items()}
 
     def step():
         for p in vi.parameters():
             p.grad = None
         vi.loss(data).backward()
 
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters * 1e3
+    def enc_only():
+        for p in enc.parameters():
+            p.grad = None
+        mu, lv = enc(data["measurements"], data["actions"], data["masks"])
+        (mu.sum() + lv.sum()).backward()
+
+    def timed(fn):
+        fn()
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    ms, ms_enc = timed(step), timed(enc_only)
+    flops = N_PER_GPU * LSTM_MFLOP_PER_TRAJ * 1e6
+    out = {"ms": ms, "trajectories_per_s": N_PER_GPU / ms * 1e3,
+           "what": "EncoderLSTM(81->160, fp32 MFMA) + rk4 solve + fused readout / masked SSE + MC-KL, fwd+bwd, %d patients" % N_PER_GPU,
+           "roofline": {"bound": "mfma", "kernel": "lstm_fwd / lstm_bwd (v_mfma_f32_16x16x4_f32) + weight-gradient GEMM",
+                        "achieved": flops / (ms_enc * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (ms_enc * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "flop_per_trajectory": LSTM_MFLOP_PER_TRAJ * 1e6, "encoder_fwd_bwd_ms": ms_enc,
+                        "frac_of_whole_step": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}}
+    if not cpu:
+        return out, lambda: None
+    # the parity pass on the GPU (elbo=False: no sampling noise in the way), first n_cpu patients
+    small = {k: v[:, :n_cpu].contiguous() for k, v in host.items()}
+    vi_p = model.VariationalInference(enc, dec, elbo=False)
+    for p in vi_p.parameters():
+        p.grad = None
+    loss_g = vi_p.loss({k: v.to(dev) for k, v in small.items()})
+    loss_g.backward()
+    keys = ("lstm.weight_ih_l0", "lstm.weight_hh_l0", "lin.weight", "output_function.0.weight", "ode.ml_net.0.weight")
+    gp = dict(list(enc.named_parameters()) + list(dec.named_parameters()))
+    g_gpu = {k: gp[k].grad.detach().cpu().clone() for k in keys}
+    loss_gpu = loss_g.item()
+    state = ({k: v.cpu() for k, v in enc.state_dict().items()}, {k: v.cpu() for k, v in dec.state_dict().items()})
+
+    def cpu_legs():
+        from oracle import vi as ovi
+        from oracle.encoder import EncoderLSTMOracle
+        torch.set_num_threads(host_cores())
+        enc_o = EncoderLSTMOracle(OBS + 1, OBS * 2, D)
+        dec_o = ovi.DecoderOracle(OBS, D, (T - 1) * synth.STEP, synth.STEP, method="rk4")
+        enc_o.load_state_dict(state[0])
+        dec_o.load_state_dict(state[1])
+        times = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            enc_o.zero_grad()
+            dec_o.zero_grad()
+            loss_o = ovi.vi_loss(enc_o, dec_o, small, elbo=False)
+            loss_o.backward()
+            times.append(time.perf_counter() - t0)
+            log("full-step cpu rep %d: %.2f s (%d patients)" % (i, times[-1], n_cpu))
+        med = statistics.median(times[1:])
+        out["cpu_baseline"] = {"value": n_cpu / med, "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "first %d of %d patients, oracle encoder + rk4 + readout + masked SSE (elbo=False), "
+                                         "fwd + autograd bwd, 1 warm-up + 3 reps (median %.3f s)" % (n_cpu, N_PER_GPU, med)}
+        op = dict(list(enc_o.named_parameters()) + list(dec_o.named_parameters()))
+        rels = {k: _rel(g_gpu[k], op[k].grad) for k in keys}
+        out["parity"] = {"vs": "CPU oracle pipeline, first %d patients, T=%d, obs=%d, elbo=False" % (n_cpu, T, OBS),
+                         "loss_rel": abs(loss_gpu - loss_o.item()) / abs(loss_o.item()), "grad_rel": rels,
+                         "tolerance": {"loss_rel": 2e-4, "grad_rel": 2e-3}}
+        out["parity"]["ok"] = bool(out["parity"]["loss_rel"] <= 2e-4 and max(rels.values()) <= 2e-3)
+
+    return out, cpu_legs
 
 
-def dopri5_step(dev, rank, dist=None, iters=3):
-    """Extra (not the headline; BASELINE config 3 per GPU): the same patients through the adaptive Dormand-Prince solve
-    (rtol 1e-7, atol 1e-8, per-rank batch-global controller) + its tape adjoint, and -- when distributed -- the all-reduce
-    of the parameter gradients.  Max over ranks, like the headline."""
-    from hode import synth, adaptive
-    inp = synth.solver_inputs(N_PER_GPU, T, D, seed=synth.SEED + rank)
-    w, b = synth.default_ml_weights(D)
-    theta = torch.tensor((2.0, 2.0) + (1.0,) * 11 + (0.0,) * 3, device=dev)
-    chan = inp["actions"][..., 0]
-    dosage = chan.max(dim=0)[0].to(dev)
-    times = (torch.nonzero((chan != 0).t())[:, 1].reshape(N_PER_GPU, -1) * synth.STEP).float().to(dev)
+# ---------------------------------------------------------------------------------------------------------------------
+# extra block 2: dopri5 (BASELINE config 3 per GPU)
+
+def dopri5_step(dev, rank, prob, dist=None, iters=3, cpu=True, n_cpu=256, n_par=128):
+    """The same patients through the adaptive Dormand-Prince solve (rtol 1e-7, atol 1e-8, per-rank batch-global controller)
+    + its tape adjoint, and -- when distributed -- the all-reduce of the parameter gradients.  Max over ranks."""
+    import torch
+    from hode import adaptive
+    inp = prob["inp"]
+    theta = prob["theta"].to(dev)
+    dosage, times = prob["dosage"].to(dev), prob["times"].to(dev)
     y0 = inp["z0"].to(dev).requires_grad_(True)
-    wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    wg, bg = prob["w"].to(dev).requires_grad_(True), prob["b"].to(dev).requires_grad_(True)
     t = inp["t"].to(dev)
-    cot = torch.randn(T, N_PER_GPU, D, device=dev)
+    cot = prob["cot"].to(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    split = {"fwd": [], "bwd": []}
 
-    def step():
+    def step(detach=False):
         y0.grad = wg.grad = bg.grad = None
-        h = adaptive.roche_dopri5(y0, theta, wg, bg, t, dosage, times, rtol=1e-7, atol=1e-8)
+        ev[0].record()
+        h = adaptive.roche_dopri5(y0, theta, wg, bg, t, dosage, times, rtol=1e-7, atol=1e-8, detach_first_step=detach)
+        ev[1].record()
         (h * cot).sum().backward()
+        ev[2].record()
         if dist is not None:
             flat = torch.cat([wg.grad.flatten(), bg.grad.flatten()])
             dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        return h
 
     step()
     if dist is not None:
@@ -188,6 +328,9 @@ def dopri5_step(dev, rank, dist=None, iters=3):
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
+        torch.cuda.synchronize()
+        split["fwd"].append(ev[0].elapsed_time(ev[1]))
+        split["bwd"].append(ev[1].elapsed_time(ev[2]))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -196,12 +339,75 @@ def dopri5_step(dev, rank, dist=None, iters=3):
         tt = torch.tensor([ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms = float(tt.item())
-    return ms, dict(adaptive.last_stats)
+    st = dict(adaptive.last_stats)
+    attempts = st["n_accepted"] + st["n_rejected"]
+    fwd_ms, bwd_ms = statistics.mean(split["fwd"]), statistics.mean(split["bwd"])
+    world = 1 if dist is None else dist.get_world_size()
+    # algorithmic bytes of one attempt: read y_n and f_n (FSAL), write the candidate y_{n+1} and its k7 = 16 D bytes per
+    # patient; of the sweep per accepted step: read y_n (4D) -- plus h and grad_h once (8 T D + 4 D, as for rk4)
+    att_bytes = N_PER_GPU * 16 * D
+    us_att = fwd_ms * 1e3 / max(attempts, 1)
+    out = {"ms": ms, "trajectories_per_s": N_PER_GPU * world / ms * 1e3, "rtol": 1e-7, "atol": 1e-8,
+           "n_accepted": st["n_accepted"], "n_rejected": st["n_rejected"], "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+           "what": "dopri5 solve (one launch per attempted step, batch-global controller per rank) + tape adjoint incl. the "
+                   "derivative of the first step size" + ("" if dist is None else " + rccl all-reduce of the parameter grads"),
+           "roofline": {"bound": "hbm", "kernel": "dp_fwd_kernel<12, 4> (one attempt per launch)", "achieved": att_bytes / (us_att * 1e-6) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": att_bytes / (us_att * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "bytes_per_launch": att_bytes, "avg_launch_us": us_att, "attempts": attempts,
+                        "note": "us per attempt = forward wall time on the stream / attempts (launch floor ~1.2 us included); "
+                                "the attempt is issue / latency bound, not traffic bound (DESIGN.md section 5)"}}
+    if not cpu or rank != 0:
+        return out, lambda: None
+    # ---- parity: the oracle's accepted-step algebra replayed along THIS run's tape on a slice of the patients (the
+    # first step size detached on both sides: its derivative is batch-global and cannot be formed from a slice;
+    # tests/test_hip_dopri5.py pins that term on whole batches).  GPU pass now, CPU legs later.
+    adaptive.keep_workspace = True
+    try:
+        h = step(detach=True)
+        tape = adaptive.read_tape()
+    finally:
+        adaptive.keep_workspace = False
+    h_gpu, gy0_gpu = h.detach()[:, :n_par].cpu(), y0.grad[:n_par].cpu().clone()
+
+    def cpu_legs():
+        from oracle.solvers import odeint, odeint_dopri5_replay
+        torch.set_num_threads(host_cores())
+        f = oracle_rhs(prob)
+        f.set_action(inp["actions"][:, :n_par])
+        y0c = inp["z0"][:n_par].clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        hr = odeint_dopri5_replay(f, y0c, inp["t"], 1e-7, 1e-8, list(zip(tape["t"], tape["dt"])), False)
+        (hr * prob["cot"][:, :n_par]).sum().backward()
+        log("dopri5 replay oracle on %d patients along %d accepted steps: %.1f s" % (n_par, len(tape["t"]), time.perf_counter() - t0))
+        err = (h_gpu - hr.detach()).double()
+        out["parity"] = {"vs": "CPU oracle step algebra replayed along this run's (t_n, dt_n) tape, first %d patients, first "
+                               "step size detached on both sides" % n_par,
+                         "mse": float((err ** 2).mean()), "max_abs": float(err.abs().max()),
+                         "grad_y0_rel": _rel(gy0_gpu, y0c.grad), "tolerance": {"mse": 1e-5, "grad_rel": 1e-3}}
+        out["parity"]["ok"] = bool(out["parity"]["mse"] <= 1e-5 and out["parity"]["grad_y0_rel"] <= 1e-3)
+        # CPU baseline: the free-running oracle (its own controller) on a bounded sample
+        f.set_action(inp["actions"][:, :n_cpu])
+        times_, stc = [], {}
+        for i in range(2):
+            y0o = inp["z0"][:n_cpu].clone().requires_grad_(True)
+            f.zero_grad()
+            t0 = time.perf_counter()
+            ho = odeint(f, y0o, inp["t"], method="dopri5", rtol=1e-7, atol=1e-8, stats=stc)
+            (ho * prob["cot"][:, :n_cpu]).sum().backward()
+            times_.append(time.perf_counter() - t0)
+            log("dopri5 cpu rep %d: %.1f s (%d patients, %d + %d attempts)" % (i, times_[-1], n_cpu, stc["n_accepted"], stc["n_rejected"]))
+        out["cpu_baseline"] = {"value": n_cpu / times_[-1], "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "first %d of %d patients (own batch-global controller: %d accepted + %d rejected attempts), "
+                                         "dopri5 rtol 1e-7 atol 1e-8, fwd + autograd bwd, 1 warm-up + 1 rep (%.1f s)"
+                                         % (n_cpu, N_PER_GPU, stc["n_accepted"], stc["n_rejected"], times_[-1])}
+
+    return out, cpu_legs
 
 
 def kernel_times(plan, iters=20):
     """Average duration of the forward kernel and of the adjoint kernel ALONE (no memset, no partial fold -- the quantity
     rocprofv3's kernel stats report), plus the whole backward call, from HIP events on the launch stream."""
+    import torch
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
     for i in range(iters):
         ev[i][0].record()
@@ -223,16 +429,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip every CPU leg (baselines and parity)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the full_training_step and dopri5_step blocks")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--lanes", type=int, default=0, help="force lanes per patient (1|4), 0 = library default")
     ap.add_argument("--no-theta-grad", action="store_true", help="skip the 13 expert-constant gradients")
     ap.add_argument("--graph-allreduce", action="store_true", help="N>1: capture the gradient all-reduce inside the step's HIP graph")
     ap.add_argument("--sync-allreduce", action="store_true", help="N>1: wait for each step's gradient all-reduce before the next solve")
     ap.add_argument("--no-tape", action="store_true", help="backward re-integrates the expert stages instead of reading the forward's tape")
-    ap.add_argument("--full-step", action="store_true", help="also time one full training step (encoder + loss) as an extra field")
-    ap.add_argument("--dopri5", action="store_true", help="also time the adaptive (dopri5) solve + adjoint at the same shape (BASELINE config 3 per GPU) as an extra field")
+    ap.add_argument("--full-step", action="store_true", help="(default now) kept for compatibility")
+    ap.add_argument("--dopri5", action="store_true", help="(default now) kept for compatibility")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)  # does not return
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner on
     # communicator creation): keep the real stdout aside for the result line and point fd 1 at stderr for everything else.
@@ -240,23 +453,26 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device visible (the solver path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    n_ranks = 1
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: always take the distributed path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)  # the rank count as the collective itself sees it
+        n_ranks = int(ones.item())
+        log("rank %d: RCCL communicator up, all-reduce of ones = %d ranks" % (rank, n_ranks))
 
-    plan, inp, wb = build_plan(dev, rank, lanes=args.lanes, need_theta=not args.no_theta_grad, tape=not args.no_tape)
+    prob = solver_problem(rank)
+    plan = build_plan(dev, prob, lanes=args.lanes, need_theta=not args.no_theta_grad, tape=not args.no_tape)
     use_graph = not args.no_graph
     log("rank %d: plan built (B=%d, T=%d, D=%d)" % (rank, N_PER_GPU, T, D))
     overlap = dist is not None and use_graph and not args.sync_allreduce and not args.graph_allreduce
@@ -282,20 +498,17 @@ def main():
     # while the solver kernels of step k+1 run -- in the full training step the same bucket is exchanged under the
     # encoder's BPTT, which follows the solver backward.  Every exchange completes inside the timed region (fence()).
     # --sync-allreduce serialises it instead (replay -> all-reduce -> replay).
-    works = [None, None]
-    state = {"k": 0}
+    from hode.parallel import AlternatingExchange
+    exchange = AlternatingExchange(lambda buf: dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True)) if overlap else None
 
     def step():
         if step_graph is not None:
             step_graph.replay()
             return
         if overlap:
-            i = state["k"] & 1
-            if works[i] is not None:
-                works[i].wait()  # stream-side wait for the exchange issued two steps ago before its bucket is refilled
-            plan.replay(i)       # the graph captured for bucket i
-            works[i] = dist.all_reduce(plan.buckets[i], op=dist.ReduceOp.AVG, async_op=True)
-            state["k"] += 1
+            i = exchange.acquire()          # waits (stream-side) for the exchange issued two steps ago on this bucket
+            plan.replay(i)                  # the graph captured for bucket i
+            exchange.release(i, plan.buckets[i])
             return
         if use_graph:
             plan.replay()
@@ -306,9 +519,8 @@ def main():
 
     def fence():
         if dist is not None:
-            for w in works:
-                if w is not None:
-                    w.wait()
+            if exchange is not None:
+                exchange.drain()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -327,10 +539,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    dp = dopri5_step(dev, rank, dist) if args.dopri5 else None  # every rank takes part (its all-reduce is collective)
-    out = None
+    extras = not args.headline_only
+    cpu = not args.no_cpu and world == 1
+    # ---- every GPU measurement first (the card clocks down while the host runs the CPU legs), then the CPU legs
+    gpu = kt = None
     if rank == 0:
-        fwd_s, bwd_s, bwd_call_s = kernel_times(plan)
+        kt = kernel_times(plan)
+        # what the timed kernels left in HBM for one step (single rank: the bucket IS this rank's gradient)
+        if use_graph:
+            plan.replay(0)
+        else:
+            plan.step()
+        torch.cuda.synchronize()
+        gpu = {"h": plan.h.clone(), "gy0": plan.grad_y0.clone(), "gw": plan.grad_w.clone(), "gb": plan.grad_b.clone(),
+               "gth": plan.grad_theta.clone(),
+               "what": "split layout%s, %s" % ("" if args.no_tape else " + stage tape", "hipGraph replay" if use_graph else "eager launches")}
+    dp, dp_cpu = dopri5_step(dev, rank, prob, dist, cpu=cpu) if extras else (None, None)  # every rank takes part (collective)
+    if rank == 0:
+        fs, fs_cpu = full_training_step(dev, cpu=cpu) if extras else (None, None)
+        fwd_s, bwd_s, bwd_call_s = kt
         ms = elapsed / args.steps * 1e3
         total = N_PER_GPU * world
         ach = plan.bwd_bytes / bwd_s / 1e9
@@ -351,12 +578,12 @@ def main():
                                    "+ discrete-adjoint kernel (split expert/learned wave pipelines)" % (N_PER_GPU, T),
                        "patients_total": total, "launch": "hipGraph" if use_graph else "eager",
                        "lanes_per_patient": args.lanes or "auto", "theta_grad": not args.no_theta_grad,
-                       "parallelism": "dp%d" % world,
+                       "parallelism": "dp%d" % world, "n_ranks": n_ranks,
                        "grad_exchange": None if dist is None else ("rccl all-reduce(AVG), async under the next solve" if overlap
                                                                    else ("rccl all-reduce(AVG), captured in the step graph" if in_graph
                                                                          else "rccl all-reduce(AVG), serialised"))},
             "roofline": {"bound": "hbm", "kernel": "split_bwd_kernel<12, rk4> (adjoint kernel alone; the whole backward call incl. "
-                                                      "accumulator memset and partial folds is bwd_call_us)", "achieved": ach,
+                                                      "the partial fold is bwd_call_us)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": plan.bwd_bytes, "avg_launch_us": bwd_s * 1e6, "bwd_call_us": bwd_call_s * 1e6,
                          "fwd": {"bytes_per_launch": plan.fwd_bytes, "avg_launch_us": fwd_s * 1e6,
@@ -366,24 +593,24 @@ def main():
         tr = pmc_traffic(tape=not args.no_tape)
         if tr is not None:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr["source"]
+            out["roofline"]["traffic_source"] = "committed profile " + tr["source"] + " (rocprofv3 --pmc, not collected in this run)"
+            if tr.get("valu_active_frac") is not None:
+                # the second roofline of this kernel: it is issue bound: share of the wave's cycles
+                # in which it issues a VALU instruction, from the same committed --pmc pass
+                out["roofline"]["issue"] = {"valu_active_frac": tr["valu_active_frac"], "source": tr["source"]}
         if not args.no_tape:
             # deliberate recompute <-> traffic trade: the forward leaves the 3 intermediate expert stage
             # states of every step (16 B each) and the backward reads them back instead of re-integrating
             out["roofline"]["tape_bytes_per_launch"] = (T - 1) * 3 * N_PER_GPU * 16
             out["config"]["stage_tape"] = True
-        if args.full_step:
-            ms_full = full_step_ms(dev)
-            out["full_training_step"] = {"ms": ms_full, "trajectories_per_s": N_PER_GPU / ms_full * 1e3,
-                                         "what": "EncoderLSTM(81->160, MFMA) + rk4 solve + readout + masked SSE + MC-KL, fwd+bwd"}
-        if dp is not None:
-            out["dopri5_step"] = {"ms": dp[0], "trajectories_per_s": N_PER_GPU * world / dp[0] * 1e3, "rtol": 1e-7, "atol": 1e-8,
-                                  "n_accepted": dp[1]["n_accepted"], "n_rejected": dp[1]["n_rejected"],
-                                  "what": "dopri5 solve (one launch per attempted step, batch-global controller per rank) + "
-                                          "tape adjoint" + ("" if dist is None else " + rccl all-reduce of the parameter grads")}
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(inp, wb)
+        if cpu:
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(prob, gpu)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if extras:
+            fs_cpu()
+            dp_cpu()
+            out["full_training_step"] = fs
+            out["dopri5_step"] = dp
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)

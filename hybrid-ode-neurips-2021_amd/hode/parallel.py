@@ -91,3 +91,40 @@ class GradBucket:
         if failed is None:
             return self.flat
         return bool(self._buf[self.numel].item() > 0.0)
+
+
+class AlternatingExchange:
+    """Pipelines a small asynchronous collective under the NEXT step's compute with two (or ``n``) buffers.
+
+    Step k fills buffer ``i = k % n`` and hands it to ``issue(buf)`` (e.g. ``dist.all_reduce(buf, async_op=True)``), which
+    returns a work handle; the exchange runs while step k+1 fills the other buffer.  ``acquire()`` returns the buffer
+    index for the coming step after waiting for the exchange issued on it ``n`` steps ago -- a buffer is never refilled
+    while its collective is in flight; ``drain()`` waits for everything outstanding, so a caller that drains before it
+    stops its clock has every exchange inside the timed region (bench.py).
+    """
+
+    def __init__(self, issue, n=2):
+        self.issue, self.n = issue, n
+        self.works = [None] * n
+        self.k = self.issued = self.completed = 0
+
+    def _finish(self, i):
+        if self.works[i] is not None:
+            self.works[i].wait()
+            self.works[i] = None
+            self.completed += 1
+
+    def acquire(self):
+        i = self.k % self.n
+        self._finish(i)
+        return i
+
+    def release(self, i, buf):
+        assert i == self.k % self.n and self.works[i] is None, "release() must follow the acquire() of the same step"
+        self.works[i] = self.issue(buf)
+        self.issued += 1
+        self.k += 1
+
+    def drain(self):
+        for i in range(self.n):
+            self._finish(i)
