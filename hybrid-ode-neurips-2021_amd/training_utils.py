@@ -181,54 +181,55 @@ def _posterior_scores(model, data, t0, mc_itr, real, expert_dim):
     return se_z0, sse_x, n_x, crps_z0, crps_x
 
 
+def _rmse_with_bootstrap(sq_err, resample_observed_only=True):
+    """sqrt(mean) of a 1-D tensor of squared errors over its non-NaN entries (NaN = nothing observed) and the bootstrap
+    standard deviation of that estimate (``bootstrap_RMSE``).  ``evaluate`` resamples the observed entries only
+    (reference :186-189); ``evaluate_horizon`` hands the raw row to the bootstrap (reference :272), so a forecast step
+    with an unobserved patient reports a NaN spread there, as the reference does."""
+    seen = sq_err[~torch.isnan(sq_err)]
+    return torch.sqrt(seen.mean()).item(), bootstrap_RMSE(seen if resample_observed_only else sq_err)
+
+
+def _mean_with_standard_error(values, axis=None):
+    """mean and standard error of the mean (population std / sqrt(count)) along ``axis``."""
+    count = values.size if axis is None else values.shape[axis]
+    return np.mean(values, axis=axis), np.std(values, axis=axis) / np.sqrt(count)
+
+
 def evaluate(model, data_generator, batch_size, t0, mc_itr=50, real=False):
+    """Reference ``training_utils.evaluate`` (:100-201): per test chunk the point-estimate errors and the ensemble CRPS
+    of ``mc_itr`` posterior draws; prints the four ``name,value,sd`` lines and returns
+    ``(rmse_z0, rmse_z0_sd, cprs_z0, rmse_x, rmse_x_sd, cprs_x)``."""
+    per_chunk = {"se_z0": [], "mse_x": [], "crps_z0": [], "crps_x": []}
     with torch.no_grad():
-        total_rmse_z0, total_rmse_x, total_cprs_z0, total_cprs_x = [], [], [], []
         for chunk in range(data_generator.test_size // batch_size):
             data = data_generator.get_split("test", batch_size, chunk)
             se_z0, sse_x, n_x, crps_z0, crps_x = _posterior_scores(model, data, t0, mc_itr, real, data_generator.expert_dim)
-            total_rmse_z0.append(se_z0)
-            total_rmse_x.append(sse_x.sum(dim=0) / n_x.sum(dim=0))
-            total_cprs_z0.append(crps_z0.cpu().numpy())
-            total_cprs_x.append(crps_x.mean(dim=0).cpu().numpy())
-
-        total_rmse_z0 = torch.cat(total_rmse_z0).cpu()
-        rmse_z0 = torch.sqrt(torch.mean(total_rmse_z0)).item()
-        rmse_z0_sd = bootstrap_RMSE(total_rmse_z0)
-
-        total_cprs_z0 = np.concatenate(total_cprs_z0)
-        cprs_z0 = np.mean(total_cprs_z0)
-        cprs_z0_sd = np.std(total_cprs_z0) / np.sqrt(len(total_cprs_z0))
-
-        total_rmse_x = torch.cat(total_rmse_x).cpu()
-        total_rmse_x = total_rmse_x[~torch.isnan(total_rmse_x)]
-        rmse_x = torch.sqrt(torch.mean(total_rmse_x)).item()
-        rmse_x_sd = bootstrap_RMSE(total_rmse_x)
-
-        total_cprs_x = np.concatenate(total_cprs_x)
-        cprs_x = np.mean(total_cprs_x)
-        cprs_x_sd = np.std(total_cprs_x) / np.sqrt(len(total_cprs_x))
-
-        print("rmse_z0,{:.4f},{:.4f}".format(rmse_z0, rmse_z0_sd))
-        print("rmse_x,{:.4f},{:.4f}".format(rmse_x, rmse_x_sd))
-        print("cprs_z0,{:.4f},{:.4f}".format(cprs_z0, cprs_z0_sd))
-        print("cprs_x,{:.4f},{:.4f}".format(cprs_x, cprs_x_sd))
-        return rmse_z0, rmse_z0_sd, cprs_z0, rmse_x, rmse_x_sd, cprs_x
+            per_chunk["se_z0"].append(se_z0.cpu())
+            per_chunk["mse_x"].append((sse_x.sum(dim=0) / n_x.sum(dim=0)).cpu())  # per patient, over the horizon
+            per_chunk["crps_z0"].append(crps_z0.cpu().numpy())
+            per_chunk["crps_x"].append(crps_x.mean(dim=0).cpu().numpy())
+    rmse_z0, rmse_z0_sd = _rmse_with_bootstrap(torch.cat(per_chunk["se_z0"]))
+    rmse_x, rmse_x_sd = _rmse_with_bootstrap(torch.cat(per_chunk["mse_x"]))
+    cprs_z0, cprs_z0_sd = _mean_with_standard_error(np.concatenate(per_chunk["crps_z0"]))
+    cprs_x, cprs_x_sd = _mean_with_standard_error(np.concatenate(per_chunk["crps_x"]))
+    for name, value, sd in (("rmse_z0", rmse_z0, rmse_z0_sd), ("rmse_x", rmse_x, rmse_x_sd),
+                            ("cprs_z0", cprs_z0, cprs_z0_sd), ("cprs_x", cprs_x, cprs_x_sd)):
+        print("{},{:.4f},{:.4f}".format(name, value, sd))
+    return rmse_z0, rmse_z0_sd, cprs_z0, rmse_x, rmse_x_sd, cprs_x
 
 
 def evaluate_horizon(model, data_generator, batch_size, t0, mc_itr=10, real=False):
+    """Reference ``training_utils.evaluate_horizon`` (:204-279): the same scores resolved per forecast step."""
+    mse_x, crps_x_all = [], []
     with torch.no_grad():
-        total_rmse_x, total_cprs_x = [], []
         for chunk in range(data_generator.test_size // batch_size):
             data = data_generator.get_split("test", batch_size, chunk)
             _, sse_x, n_x, _, crps_x = _posterior_scores(model, data, t0, mc_itr, real, data_generator.expert_dim)
-            total_rmse_x.append((sse_x / n_x).cpu())          # T', B
-            total_cprs_x.append(crps_x.cpu().numpy())          # T', B
-
-        total_rmse_x = torch.cat(total_rmse_x, dim=1)
-        rmse_x = torch.sqrt(torch.nanmean(total_rmse_x, dim=1)).numpy()
-        rmse_x_sd = np.array([bootstrap_RMSE(total_rmse_x[i]) for i in range(rmse_x.shape[0])])
-        total_cprs_x = np.concatenate(total_cprs_x, axis=1)
-        cprs_x = np.mean(total_cprs_x, axis=1)
-        cprs_x_sd = np.std(total_cprs_x, axis=1) / np.sqrt(total_cprs_x.shape[1])
-        return {"rmse_x": rmse_x, "rmse_x_sd": rmse_x_sd, "cprs_x": cprs_x, "cprs_x_sd": cprs_x_sd}
+            mse_x.append((sse_x / n_x).cpu())        # (T', B): NaN where a patient has no observation at that step
+            crps_x_all.append(crps_x.cpu().numpy())  # (T', B)
+    mse_x = torch.cat(mse_x, dim=1)
+    per_step = [_rmse_with_bootstrap(mse_x[i], resample_observed_only=False) for i in range(mse_x.shape[0])]
+    cprs_x, cprs_x_sd = _mean_with_standard_error(np.concatenate(crps_x_all, axis=1), axis=1)
+    return {"rmse_x": np.array([r for r, _ in per_step], dtype=np.float32), "rmse_x_sd": np.array([sd for _, sd in per_step]),
+            "cprs_x": cprs_x, "cprs_x_sd": cprs_x_sd}

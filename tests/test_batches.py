@@ -1,0 +1,74 @@
+"""hode.batches.DeviceFolds against a literal restatement of the reference generators' slicing (dataloader.py:272-341)."""
+import numpy as np
+import pytest
+import torch
+
+from hode.batches import DeviceFolds
+
+
+def _raw(T=7, N=23, obs=5, D=6, statics=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    d = {"measurements": torch.randn(T, N, obs, generator=g), "actions": torch.rand(T, N, 1, generator=g),
+         "latents": torch.randn(T, N, D, generator=g), "masks": (torch.rand(T, N, obs, generator=g) < 0.5).float()}
+    if statics:
+        d["statics"] = torch.rand(T, N, 3, generator=g)
+    return d
+
+
+def _reference_folds(d, val, test):
+    n = d["measurements"].shape[1]
+    tr = n - val - test
+    return ({k: v[:, :tr] for k, v in d.items()}, {k: v[:, tr:tr + val] for k, v in d.items()},
+            {k: v[:, tr + val:] for k, v in d.items()})
+
+
+@pytest.mark.parametrize("statics", [False, True])
+def test_splits_and_minibatches_equal_the_reference_slicing(statics):
+    d = _raw(statics=statics)
+    f = DeviceFolds(d["measurements"], d["actions"], d["latents"], d["masks"], 5, 4, statics=d.get("statics"), device="cpu")
+    tr, va, te = _reference_folds(d, 5, 4)
+    assert (f.train_size, f.val_size, f.test_size, f.expert_dim, f.latent_dim) == (14, 5, 4, 4, 6)
+    for fold, ref in (("train", tr), ("val", va), ("test", te)):
+        for bs in (2, 3):
+            for chunk in range(ref["measurements"].shape[1] // bs):
+                got = f.get_split(fold, bs, chunk)
+                assert set(got) == set(ref)
+                for k in ref:
+                    assert torch.equal(got[k], ref[k][:, chunk * bs:(chunk + 1) * bs]) and got[k].is_contiguous()
+    whole = f.get_split("val", 5, 0)
+    assert whole["masks"].data_ptr() == f.data_val["masks"].data_ptr()  # a whole fold is handed out without a copy
+    # random minibatches: the reference draws np.random.choice(N, k, replace=False) (dataloader.py:297-299)
+    np.random.seed(3)
+    got = [f.get_mini_batch("train", 6) for _ in range(3)]
+    np.random.seed(3)
+    for g in got:
+        idx = torch.tensor(np.random.choice(14, 6, replace=False), dtype=torch.int64)
+        for k in tr:
+            assert torch.equal(g[k], tr[k][:, idx, :]) and g[k].is_contiguous()
+
+
+def test_set_train_size_device_index_mode_and_generator_adapter():
+    d = _raw(N=30)
+    f = DeviceFolds(d["measurements"], d["actions"], d["latents"], d["masks"], 5, 5, device="cpu", index_rng="device")
+    f.set_train_size(17)  # counts all folds, like DataGeneratorRoche.set_train_size
+    assert f.train_size == 7 and f.get_split("train", 7, 0)["latents"].shape == (7, 7, 6)
+    b = f.get_mini_batch("train", 5)
+    cols = {tuple(b["latents"][:, i].flatten().tolist()) for i in range(5)}
+    assert len(cols) == 5  # without replacement
+    assert all(any(torch.equal(b["latents"][:, i], d["latents"][:, j]) for j in range(7)) for i in range(5))
+
+    class _Dg:  # what a pickled reference generator exposes
+        measurements, actions, latents, masks = d["measurements"], d["actions"], d["latents"], d["masks"]
+        val_size, test_size, expert_dim = 4, 6, 4
+
+    g = DeviceFolds.from_generator(_Dg(), "cpu")
+    assert g.train_size == 20 and torch.equal(g.get_split("test", 6, 0)["measurements"], d["measurements"][:, 24:])
+
+
+def test_synthetic_folds_have_the_benchmark_distribution():
+    f = DeviceFolds.synthetic(400, 20, 8, 12, 50, 50, "cpu", seed=1)
+    b = f.get_split("train", 100, 1)
+    assert b["measurements"].shape == (20, 100, 8) and b["latents"].shape == (20, 100, 12)
+    chan = f.actions[..., 0]
+    assert bool(((chan != 0).sum(dim=0) == 1).all()) and bool((chan[-1] == 0).all()) and float(chan.max()) <= 10.01
+    assert 0.4 < float(f.masks.mean()) < 0.6 and abs(float(f.latents[0].mean()) - 0.01) < 2e-3
