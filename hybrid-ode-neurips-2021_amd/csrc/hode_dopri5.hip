@@ -102,35 +102,54 @@ int dp_dispatch_dim(const hode_solve_desc* d, const DpLaunch& L, const DpArgs& a
   return hode::fail(HODE_E_UNSUPPORTED, "dopri5: latent_dim %d has no compiled kernel (have 4, 6, 8, 12)", d->latent_dim);
 }
 
-int check_dp(const hode_solve_desc* d, bool bwd) {
+bool is_neural(const hode_solve_desc* d) { return d && d->struct_size == sizeof(hode_solve_desc) && d->rhs_kind == HODE_RHS_NEURAL; }
+
+// argument checks shared by both rhs families
+int check_common(const hode_solve_desc* d, bool bwd) {
   if (!d) return hode::fail(HODE_E_NULL, "descriptor is NULL");
   if (d->struct_size != sizeof(hode_solve_desc))
     return hode::fail(HODE_E_SIZE, "struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(hode_solve_desc));
-  if (d->rhs_kind != HODE_RHS_ROCHE && d->rhs_kind != HODE_RHS_ROCHE_ABLATE)
-    return hode::fail(HODE_E_UNSUPPORTED, "rhs_kind %d is not handled by the dopri5 Roche kernels", d->rhs_kind);
   if (d->batch <= 0 || d->n_times <= 0 || d->latent_dim < 4 || d->n_dose < 0 || d->max_steps <= 0)
     return hode::fail(HODE_E_SIZE, "bad sizes: batch=%d n_times=%d latent_dim=%d n_dose=%d max_steps=%d", d->batch,
                       d->n_times, d->latent_dim, d->n_dose, d->max_steps);
   if (!(d->rtol > 0) || !(d->atol >= 0)) return hode::fail(HODE_E_SIZE, "rtol must be > 0 and atol >= 0");
-  if (!d->t || !d->y0 || !d->dosage || !d->theta || !d->h || (d->n_dose > 0 && !d->dose_times))
-    return hode::fail(HODE_E_NULL, "t / y0 / dosage / dose_times / theta / h must be non-NULL");
-  if (d->latent_dim > 4 && (!d->w1 || !d->b1)) return hode::fail(HODE_E_NULL, "w1 / b1 required when latent_dim > 4");
+  if (!d->t || !d->y0 || !d->dosage || !d->h || (d->n_dose > 0 && !d->dose_times))
+    return hode::fail(HODE_E_NULL, "t / y0 / dosage / dose_times / h must be non-NULL");
   if (!d->host_n_accepted) return hode::fail(HODE_E_NULL, "host_n_accepted is required (fwd: out, bwd: in)");
   if (bwd && (!d->grad_h || !d->grad_y0)) return hode::fail(HODE_E_NULL, "grad_h / grad_y0 required by the backward");
-  const DpLayout L = dp_layout(d);
-  if (!d->workspace || d->workspace_bytes < L.total)
-    return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, L.total);
+  if (bwd && (d->flags & HODE_FLAG_OVERWRITE_GRADS))
+    return hode::fail(HODE_E_UNSUPPORTED, "HODE_FLAG_OVERWRITE_GRADS is only implemented by hode_rk_bwd");
+  if (bwd && (d->flags & HODE_FLAG_NO_TAPE))
+    return hode::fail(HODE_E_UNSUPPORTED, "the forward ran with HODE_FLAG_NO_TAPE: there is no tape to sweep");
   uintptr_t m = (uintptr_t)d->y0 | (uintptr_t)d->h | (uintptr_t)d->workspace;
   if (bwd) m |= (uintptr_t)d->grad_h | (uintptr_t)d->grad_y0;
   if (m & 15) return hode::fail(HODE_E_ALIGN, "y0 / h / grad_h / grad_y0 / workspace must be 16-byte aligned");
   return 0;
 }
 
+int check_dp(const hode_solve_desc* d, bool bwd) {
+  if (int e = check_common(d, bwd)) return e;
+  if (d->rhs_kind != HODE_RHS_ROCHE && d->rhs_kind != HODE_RHS_ROCHE_ABLATE)
+    return hode::fail(HODE_E_UNSUPPORTED, "rhs_kind %d has no dopri5 kernels (have ROCHE, ROCHE_ABLATE, NEURAL)", d->rhs_kind);
+  if (!d->theta) return hode::fail(HODE_E_NULL, "theta must be non-NULL");
+  if (d->latent_dim > 4 && (!d->w1 || !d->b1)) return hode::fail(HODE_E_NULL, "w1 / b1 required when latent_dim > 4");
+  const DpLayout L = dp_layout(d);
+  if (!d->workspace || d->workspace_bytes < L.total)
+    return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, L.total);
+  return 0;
+}
+
 }  // namespace
 
-extern "C" size_t hode_dopri5_workspace_bytes(const hode_solve_desc* d) { return dp_layout(d).total; }
+extern "C" size_t hode_dopri5_workspace_bytes(const hode_solve_desc* d) {
+  return is_neural(d) ? hode::neural_dopri5_workspace_bytes(d) : dp_layout(d).total;
+}
 
 extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
+  if (is_neural(d)) {
+    if (int e = check_common(d, false)) return e;
+    return hode::neural_dopri5(d, false, (hipStream_t)stream);
+  }
   if (int e = check_dp(d, false)) return e;
   hipStream_t s = (hipStream_t)stream;
   const DpLayout lay = dp_layout(d);
@@ -185,11 +204,11 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
 }
 
 extern "C" int hode_dopri5_bwd(const hode_solve_desc* d, void* stream) {
+  if (is_neural(d)) {
+    if (int e = check_common(d, true)) return e;
+    return hode::neural_dopri5(d, true, (hipStream_t)stream);
+  }
   if (int e = check_dp(d, true)) return e;
-  if (d->flags & HODE_FLAG_OVERWRITE_GRADS)
-    return hode::fail(HODE_E_UNSUPPORTED, "HODE_FLAG_OVERWRITE_GRADS is only implemented by hode_rk_bwd");
-  if (d->flags & HODE_FLAG_NO_TAPE)
-    return hode::fail(HODE_E_UNSUPPORTED, "the forward ran with HODE_FLAG_NO_TAPE: there is no tape to sweep");
   hipStream_t s = (hipStream_t)stream;
   const DpLayout lay = dp_layout(d);
   DpArgs a = dp_args(d, lay);
@@ -219,6 +238,7 @@ extern "C" int hode_dopri5_bwd(const hode_solve_desc* d, void* stream) {
 extern "C" int hode_dopri5_tape_offsets(const hode_solve_desc* d, size_t* out5) {
   if (!d || !out5) return hode::fail(HODE_E_NULL, "descriptor / out5 is NULL");
   if (d->struct_size != sizeof(hode_solve_desc)) return hode::fail(HODE_E_SIZE, "struct_size mismatch");
+  if (is_neural(d)) return hode::neural_dopri5_tape_offsets(d, out5);
   const DpLayout L = dp_layout(d);
   out5[0] = L.ctrl + kInitOffset;
   out5[1] = L.tape_t;

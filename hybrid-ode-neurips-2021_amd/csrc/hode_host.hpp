@@ -53,6 +53,11 @@ int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
 struct NeuralArgs;
 int launch_neural_mf(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s);  // hode_neural_mf.hip
 
+// adaptive solve of the neural rhs on the matrix cores (hode_neural_dopri5.hip)
+size_t neural_dopri5_workspace_bytes(const hode_solve_desc* d);
+int neural_dopri5_tape_offsets(const hode_solve_desc* d, size_t* out5);
+int neural_dopri5(const hode_solve_desc* d, bool bwd, hipStream_t s);
+
 // real-data rhs (hode_real.hip)
 size_t real_workspace_bytes(const hode_solve_desc* d, bool bwd);
 int real_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);

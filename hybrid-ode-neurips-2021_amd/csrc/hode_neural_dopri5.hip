@@ -1,0 +1,760 @@
+// Adaptive Dormand-Prince 5(4) solve of the NeuralODE rhs dy/dt = tanh(W2 tanh(W1 [y, Dose(t)] + b1) + b2) and its discrete
+// adjoint on the matrix cores, gfx950.
+//
+// Replaces torchdiffeq.odeint(NeuralODE, ..., method="dopri5") -- what run_simulation --method=neural reaches with the
+// reference's default solver (sim_config.py:50; rhs model.py:969-1026, call site :1116) -- and autograd's replay of its
+// accepted steps.  CPU restatement: oracle/rhs.py::NeuralRHS + oracle/solvers.py::_odeint_dopri5.
+//
+// Controller, tape and launch structure are those of the Roche kernels (hode_dopri5_kernels.hpp): one
+// launch per attempted step, controller record in device memory, batch-global RMS error norm through per-wave partials
+// that every wave of the next launch folds in a fixed order, accepted states appended to tape_y.  The rhs is
+// hode_neural_mf.hpp's register-resident MFMA product: a wave owns 16 patients, lane (g, n) holds rows 4g .. 4g+3 of
+// patient n of every vector (state, stage derivative, cotangent) -- the solver algebra around the rhs is element-wise on
+// those four registers.
+//
+// Backward: one launch walks the tape in reverse (same recurrences as dp_bwd_body_own, including sigma = d loss / d dt_0,
+// which for this rhs has no stage-time term: Dose(t) is an impulse, `times == t`, without a derivative).  The stage VJPs
+// recompute the hidden activations from the stage state instead of holding seven sets of them.  WEIGHT GRADIENTS ARE
+// ACCUMULATED ON CHIP: they are outer products summed over patients, i.e. 16 x 16 x (16 patients) matrix products per wave
+// and stage -- the pre-activation cotangents and the layer inputs are transposed through two LDS images (patient-major) so
+// that the patient index becomes the MFMA contraction index, and the wave keeps dW1 | db1 (a ones row appended to the
+// layer-1 input) and dW2 in 2 x HT accumulator tiles for the whole sweep.  One partial block per wave, folded in a fixed
+// order by ndp_fold_kernel (deterministic; no operand tape in HBM, no host GEMM).
+#include <hip/hip_runtime.h>
+
+#include "hode_dopri5_kernels.hpp"
+#include "hode_neural_mf.hpp"
+
+namespace hode {
+
+struct NdpArgs {
+  NeuralArgs nn;  // t, y0, dosage, dose_times, w1, b1, b2, w2, h, grad_h, grad_y0, B, T, K
+  DpCtrl* ctrl;
+  DpInit* init;
+  float* partials;       // [4 * n_waves]
+  float* kbuf;           // [7][B][D]
+  double* tape_t;
+  double* tape_dt;
+  int* tape_j;
+  float* tape_y;
+  float* grad_partials;  // [n_waves][NP]
+  float* grad_w1;
+  float* grad_b1;
+  float* grad_w2;
+  float* grad_b2;
+  int n_waves, max_steps, attempt, n_acc, ring;
+  float rtol, atol;
+};
+
+HODE_DEV size_t ndp_tape_row(const NdpArgs& a, int n) { return (size_t)(a.ring ? (n & 1) : n); }
+HODE_DEV v4 splat4(float x) { return v4{x, x, x, x}; }
+HODE_DEV float hsum4(const v4& v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+HODE_DEV v4 vfma4(float a, const v4& b, const v4& c) {
+  v4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(a, b[i], c[i]);
+  return r;
+}
+HODE_DEV v4 vfma4(const v4& a, const v4& b, const v4& c) {
+  v4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(a[i], b[i], c[i]);
+  return r;
+}
+
+// per-lane context: which patient / rows this lane holds
+template <int D>
+struct NdpLane {
+  int g, n, p, wave, lane;
+  bool live;
+  float lv, dosage;
+  v4 valid;  // 1 for rows < D
+  HODE_DEV NdpLane(const NdpArgs& a) {
+    lane = threadIdx.x;
+    g = lane >> 4;
+    n = lane & 15;
+    wave = blockIdx.x;
+    const int pr = wave * 16 + n;
+    live = pr < a.nn.B;
+    p = live ? pr : a.nn.B - 1;
+    lv = live ? 1.0f : 0.0f;
+    dosage = a.nn.dosage[p];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) valid[r] = (4 * g + r) < D ? 1.0f : 0.0f;
+  }
+};
+
+// sum over the wave of (u / s)^2 on the valid rows of live patients
+template <int D>
+HODE_DEV float ndp_sq_ratio(const NdpLane<D>& L, const v4& u, const v4& s) {
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float q = L.valid[r] != 0.0f ? div_f32(u[r], s[r]) : 0.0f;
+    acc = __builtin_fmaf(q, q, acc);
+  }
+  return acc * L.lv;
+}
+
+template <int D>
+HODE_DEV v4 ndp_scale(const NdpArgs& a, const v4& y) {
+  v4 s;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s[r] = a.atol + __builtin_fabsf(y[r]) * a.rtol;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------ forward kernels
+template <int D, int PHASE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ndp_fwd_kernel(NdpArgs a) {
+  constexpr int HT = NeuralMf<D>::HT;
+  const NdpLane<D> L(a);
+  const int g = L.g;
+  const size_t row = (size_t)a.nn.B * D;
+  const size_t poff = (size_t)L.p * D;
+  const float cnt = (float)a.nn.B * (float)D;
+  const int gid = blockIdx.x * 64 + threadIdx.x;
+  v4 a1[HT];
+
+  if constexpr (PHASE == 0) {
+    // init1: f0 = f(t[0], y0); h[0] = tape_y[0] = y0; kbuf[0] = f0; partials of (y0/scale)^2, (f0/scale)^2
+    NeuralMf<D> nn;
+    nn.load(a.nn, L.lane);
+    const v4 y = mf_load_rows<D>(a.nn.y0 + poff, g);
+    const v4 f0 = nn.rhs(mf_with_dose<D>(y, neural_dose(a.nn, L.p, L.dosage, a.nn.t[0]), g), a1);
+    mf_store_rows<D>(a.nn.h + poff, g, y, L.live);
+    mf_store_rows<D>(a.tape_y + poff, g, y, L.live);
+    mf_store_rows<D>(a.kbuf + poff, g, f0, L.live);
+    const v4 sc = ndp_scale<D>(a, y);
+    const float s0 = wave_sum(ndp_sq_ratio<D>(L, y, sc)), s1 = wave_sum(ndp_sq_ratio<D>(L, f0, sc));
+    if (L.lane == 0) {
+      a.partials[2 * L.wave] = s0;
+      a.partials[2 * L.wave + 1] = s1;
+    }
+  } else if constexpr (PHASE == 1) {
+    // init2: h0 from (d0, d1); f1 = f(t0 + h0, y0 + h0 f0); partial of ((f1 - f0)/scale)^2; lane 0 seeds the controller
+    NeuralMf<D> nn;
+    nn.load(a.nn, L.lane);
+    const float d0 = __builtin_sqrtf(fold_waves(a.partials, a.n_waves, 2, 0) / cnt);
+    const float d1 = __builtin_sqrtf(fold_waves(a.partials, a.n_waves, 2, 1) / cnt);
+    const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : div_f32(0.01f * d0, d1);
+    const v4 y = mf_load_rows<D>(a.nn.y0 + poff, g);
+    const v4 f0 = mf_load_rows<D>(a.kbuf + poff, g);
+    const float t0f = a.nn.t[0];
+    const v4 f1 = nn.rhs(mf_with_dose<D>(vfma4(h0, f0, y), neural_dose(a.nn, L.p, L.dosage, add_rn(t0f, h0)), g), a1);
+    const float s2 = wave_sum(ndp_sq_ratio<D>(L, f1 - f0, ndp_scale<D>(a, y)));
+    float* pout = a.partials + (size_t)2 * a.n_waves;
+    if (L.lane == 0) pout[2 * L.wave] = s2;
+    if (gid == 0) {
+      DpCtrl c;
+      c.t0 = (double)t0f;
+      c.dt = 0.0;
+      c.h0 = h0;
+      c.d1 = d1;
+      c.n_acc = 0; c.n_rej = 0; c.j_next = 1; c.done = (a.nn.T <= 1) ? 1 : 0; c.status = 0; c.attempt = 0;
+      a.ctrl[0] = c;
+      a.ctrl[1] = c;
+      DpInit in{};
+      in.h0 = h0; in.d0 = d0; in.d1 = d1;
+      *a.init = in;
+    }
+  } else {
+    // one attempt (see dp_attempt_body_own: same record handling, same dense output, same termination checks)
+    const int par = a.attempt & 1;
+    DpCtrl* cout = a.ctrl + (par ^ 1);
+    const float* pin = a.partials + (size_t)(par ^ 1) * 2 * a.n_waves;
+    float* pout = a.partials + (size_t)par * 2 * a.n_waves;
+    const FoldHead head = fold_issue(pin, a.n_waves, 2, 0);
+    const DpCtrl cin = a.ctrl[par];
+    if (cin.done) {
+      if (gid == 0) *cout = cin;
+      return;
+    }
+    NeuralMf<D> nn;
+    nn.load(a.nn, L.lane);
+    const v4 y_old = mf_load_rows<D>(a.tape_y + ndp_tape_row(a, cin.n_acc) * row + poff, g);
+    const v4 k_first = mf_load_rows<D>(a.kbuf + poff, g);
+    const v4 y_new = mf_load_rows<D>(a.tape_y + ndp_tape_row(a, cin.n_acc + 1) * row + poff, g);
+    const v4 k_last = mf_load_rows<D>(a.kbuf + 6 * row + poff, g);
+    const float t_next = a.nn.t[min(cin.j_next, a.nn.T - 1)];
+
+    DpCtrl c = cin;
+    v4 y, f0;
+    if (cin.attempt == 0) {
+      const float d2 = div_f32(__builtin_sqrtf(fold_finish(head, pin, a.n_waves, 2, 0) / cnt), cin.h0);
+      float h1;
+      if (cin.d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, cin.h0 * 1e-3f);
+      else h1 = powf(div_f32(0.01f, fmaxf(cin.d1, d2)), 0.2f);
+      c.dt = (double)fminf(100.0f * cin.h0, h1);
+      if (gid == 0) { a.init->d2 = d2; a.init->h1 = h1; }
+      y = y_old;
+      f0 = k_first;
+    } else {
+      const float ratio = __builtin_sqrtf(fold_finish(head, pin, a.n_waves, 2, 0) / cnt);
+      const double t1 = cin.t0 + cin.dt;
+      if (cin.attempt == 1 && gid == 0) a.init->first_accepted = ratio <= 1.0f ? 1 : 0;
+      if (ratio <= 1.0f) {
+        y = y_new;
+        f0 = k_last;
+        int j = cin.j_next;
+        if (j < a.nn.T && (double)t_next <= t1) {
+          const float dtf = (float)cin.dt;
+          v4 ym = y_old;
+          for (int m = 0; m < 7; ++m) ym = vfma4(dtf * kDpMid[m], mf_load_rows<D>(a.kbuf + (size_t)m * row + poff, g), ym);
+          const v4 f0i = k_first, f1i = f0, y0i = y_old, y1i = y;
+          const v4 ca = 2.0f * dtf * (f1i - f0i) - 8.0f * (y1i + y0i) + 16.0f * ym;
+          const v4 cb = dtf * (5.0f * f0i - 3.0f * f1i) + 18.0f * y0i + 14.0f * y1i - 32.0f * ym;
+          const v4 cc = dtf * (f1i - 4.0f * f0i) - 11.0f * y0i - 5.0f * y1i + 16.0f * ym;
+          const v4 cd = dtf * f0i;
+          for (; j < a.nn.T && (double)a.nn.t[j] <= t1; ++j) {
+            const float x = (float)(((double)a.nn.t[j] - cin.t0) / (t1 - cin.t0));
+            const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+            const v4 out = (((y0i + x * cd) + x2 * cc) + x3 * cb) + x4 * ca;
+            mf_store_rows<D>(a.nn.h + (size_t)j * row + poff, g, out, L.live);
+          }
+        }
+        if (gid == 0) {
+          a.tape_t[cin.n_acc] = cin.t0;
+          a.tape_dt[cin.n_acc] = cin.dt;
+          a.tape_j[2 * cin.n_acc] = cin.j_next;
+          a.tape_j[2 * cin.n_acc + 1] = j;
+        }
+        c.j_next = j;
+        c.n_acc = cin.n_acc + 1;
+        c.t0 = t1;
+      } else {
+        c.n_rej = cin.n_rej + 1;
+        y = y_old;
+        f0 = k_first;
+      }
+      c.dt = cin.dt * dp_step_factor(ratio);
+    }
+    c.attempt = cin.attempt + 1;
+
+    bool stop = false;
+    if (c.status) { c.done = 1; stop = true; }
+    if (!stop && c.j_next >= a.nn.T) { c.done = 1; stop = true; }
+    if (!stop && !(c.t0 + c.dt > c.t0)) { c.status |= HODE_STATUS_DT_UNDERFLOW; c.done = 1; stop = true; }
+    if (!stop && c.n_acc >= a.max_steps) { c.status |= HODE_STATUS_MAX_STEPS; c.done = 1; stop = true; }
+    if (stop) {
+      if (gid == 0) *cout = c;
+      return;
+    }
+
+    const float t0f = (float)c.t0, dtf = (float)c.dt, t1f = (float)(c.t0 + c.dt);
+    v4 k[7], Y = y;
+    k[0] = f0;
+#pragma unroll
+    for (int i = 2; i <= 7; ++i) {
+      const float ti = dp_stage_time(i, t0f, dtf, t1f);
+      Y = y;
+#pragma unroll
+      for (int m = 0; m < i - 1; ++m) Y = vfma4(kDpBeta[i - 2][m] * dtf, k[m], Y);
+      k[i - 1] = nn.rhs(mf_with_dose<D>(Y, neural_dose(a.nn, L.p, L.dosage, ti), g), a1);
+    }
+    // Y is y1 (FSAL row)
+    v4 err = splat4(0.f), tol;
+    bool bad = false;
+#pragma unroll
+    for (int m = 0; m < 7; ++m) err = vfma4(dtf * kDpErr[m], k[m], err);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      tol[r] = a.atol + a.rtol * fmaxf(__builtin_fabsf(y[r]), __builtin_fabsf(Y[r]));
+      bad |= !__builtin_isfinite(y[r]);
+    }
+    const float se = wave_sum(ndp_sq_ratio<D>(L, err, tol));
+    if (L.lane == 0) pout[2 * L.wave] = se;
+    mf_store_rows<D>(a.tape_y + ndp_tape_row(a, c.n_acc + 1) * row + poff, g, Y, L.live);
+    mf_store_rows<D>(a.kbuf + poff, g, k[0], L.live);
+    mf_store_rows<D>(a.kbuf + 6 * row + poff, g, k[6], L.live);
+    if ((double)(c.j_next == cin.j_next ? t_next : a.nn.t[c.j_next]) <= c.t0 + c.dt) {
+#pragma unroll
+      for (int m = 1; m < 6; ++m) mf_store_rows<D>(a.kbuf + (size_t)m * row + poff, g, k[m], L.live);
+    }
+    if (bad && L.live) atomicOr(&cout->status, HODE_STATUS_NONFINITE);
+    if (gid == 0) {
+      cout->t0 = c.t0; cout->dt = c.dt; cout->h0 = c.h0; cout->d1 = c.d1;
+      cout->n_acc = c.n_acc; cout->n_rej = c.n_rej; cout->j_next = c.j_next; cout->done = c.done; cout->attempt = c.attempt;
+      if (c.status) atomicOr(&cout->status, c.status);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ weight gradients on the matrix cores
+// dW1[h][i] += sum_n u1[h][n] e[i][n]  (i = D + 1 is a ones row: the column that collects db1),
+// dW2[o][h] += sum_n u2[o][n] a1[h][n],  db2[o] += sum_n u2[o][n]  over the wave's 16 patients n, per stage VJP.
+// The register tiles hold [row][patient] with the patient in (lane & 15), which is the MFMA's B layout with the ROW as the
+// contraction index; the outer products contract over PATIENTS, so the four operands go through LDS patient-major
+// (16-byte stores: a lane's four rows are consecutive) and come back with lane (m, kk) reading image[4c + kk][.. + m]:
+// A[m][kk] / B[kk][m] fragments of patient chunk c.  72 ds_read_b32 + 18 ds_write_b128 + 64 MFMAs per stage.
+template <int D>
+struct NeuralGradAcc {
+  static constexpr int HT = NeuralMf<D>::HT;
+  // image pitches (floats) == 16 mod 64: the fragment read of lane (m, kk) at [4c + kk][16i + m] then hits bank m + 16 kk
+  // -- all 64 lanes on different banks -- and the 16-byte writes of lane (g, n) at [n][16i + 4g] spread 4 dwords per bank
+  static constexpr int PH = ((16 * HT - 16 + 63) / 64) * 64 + 16;
+  static constexpr int PS = 16;
+  static constexpr int kLdsFloats = 16 * (2 * PH + 2 * PS);
+  static constexpr int NP = 2 * HT * 256 + 16;  // floats per wave in the partial array
+  static constexpr int GB = (D + 1) / 4, RB = (D + 1) % 4;  // tile position of the ones row behind [y, Dose]
+  v4 dW1[HT], dW2[HT], db2;
+  float *U1, *A1, *E, *U2;
+
+  HODE_DEV void init(float* lds) {
+    U1 = lds;
+    A1 = lds + 16 * PH;
+    E = lds + 32 * PH;
+    U2 = E + 16 * PS;
+#pragma unroll
+    for (int i = 0; i < HT; ++i) dW1[i] = dW2[i] = splat4(0.f);
+    db2 = splat4(0.f);
+  }
+  HODE_DEV void add(const v4 (&u1)[HT], v4 e, const v4& u2, const v4 (&a1)[HT], int g, int n) {
+    if (g == GB) e[RB] = 1.0f;
+    __syncthreads();  // the previous call's reads are done
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+      *reinterpret_cast<v4*>(U1 + n * PH + 16 * i + 4 * g) = u1[i];
+      *reinterpret_cast<v4*>(A1 + n * PH + 16 * i + 4 * g) = a1[i];
+    }
+    *reinterpret_cast<v4*>(E + n * PS + 4 * g) = e;
+    *reinterpret_cast<v4*>(U2 + n * PS + 4 * g) = u2;
+    __syncthreads();
+    const int m = n, kk = g;  // fragment coordinates of this lane
+    float eB[4], u2A[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      eB[c] = E[(4 * c + kk) * PS + m];
+      u2A[c] = U2[(4 * c + kk) * PS + m];
+    }
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float au = U1[(4 * c + kk) * PH + 16 * i + m];
+        const float ba = A1[(4 * c + kk) * PH + 16 * i + m];
+        dW1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(au, eB[c], dW1[i], 0, 0, 0);
+        dW2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(u2A[c], ba, dW2[i], 0, 0, 0);
+      }
+    }
+    db2 = db2 + u2;
+  }
+  // one block of NP floats per wave: [dW1 tiles | dW2 tiles] as [tile][lane][4], then db2[16]
+  HODE_DEV void store(float* __restrict__ out, int lane) {
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+      *reinterpret_cast<v4*>(out + ((size_t)i * 64 + lane) * 4) = dW1[i];
+      *reinterpret_cast<v4*>(out + ((size_t)(HT + i) * 64 + lane) * 4) = dW2[i];
+    }
+    v4 s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = row_sum(db2[r]);  // over the 16 patients of this row group
+    if ((lane & 15) == 0) *reinterpret_cast<v4*>(out + 2 * HT * 256 + 4 * (lane >> 4)) = s;
+  }
+  HODE_DEV static void store_zero(float* __restrict__ out, int lane) {
+    for (int i = lane; i < NP; i += 64) out[i] = 0.f;
+  }
+};
+
+// fixed-order fold of the per-wave blocks into the caller's accumulators (one wave per slot of the block)
+template <int D>
+__global__ __launch_bounds__(64) void ndp_fold_kernel(const float* __restrict__ partials, int n_waves, float* __restrict__ gw1,
+                                                      float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2) {
+  constexpr int HD = 10 * D, HT = NeuralMf<D>::HT, NP = NeuralGradAcc<D>::NP;
+  const int j = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int w = lane; w < n_waves; w += 64) s += partials[(size_t)w * NP + j];
+  s = wave_sum(s);
+  if (lane != 0) return;
+  if (j >= 2 * HT * 256) {
+    const int o = j - 2 * HT * 256;
+    if (o < D && gb2) gb2[o] += s;
+    return;
+  }
+  const int tile = j / 256, l = (j % 256) / 4, r = j % 4;
+  const int rw = 4 * (l >> 4) + r, col = l & 15;
+  if (tile < HT) {
+    const int hid = 16 * tile + rw;
+    if (hid >= HD) return;
+    if (col <= D) { if (gw1) gw1[(size_t)hid * (D + 1) + col] += s; }
+    else if (col == D + 1) { if (gb1) gb1[hid] += s; }
+  } else {
+    const int hid = 16 * (tile - HT) + col;
+    if (rw < D && hid < HD && gw2) gw2[(size_t)rw * HD + hid] += s;
+  }
+}
+
+// stage VJP with the hidden activations recomputed from the stage state; accumulates the weight gradients
+template <int D>
+HODE_DEV v4 ndp_vjp(const NeuralMf<D>& nn, NeuralGradAcc<D>& acc, const v4& e, const v4& k, const v4& gk, int g, int n) {
+  constexpr int HT = NeuralMf<D>::HT;
+  v4 a1[HT], u1[HT], u2;
+  nn.hidden(e, a1);
+  v4 av = nn.vjp(a1, k, gk, u2, u1);
+  acc.add(u1, e, u2, a1, g, n);
+  if (g == NeuralMf<D>::GD) av[NeuralMf<D>::RD] = 0.f;  // the Dose input is not a state
+  return av;
+}
+
+// ------------------------------------------------------------------------------------------------ backward sweep
+template <int D>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ndp_bwd_kernel(NdpArgs a) {
+  constexpr int HT = NeuralMf<D>::HT;
+  __shared__ __attribute__((aligned(16))) float lds[NeuralGradAcc<D>::kLdsFloats];
+  const NdpLane<D> L(a);
+  const int g = L.g;
+  NeuralMf<D> nn;
+  nn.load(a.nn, L.lane);
+  NeuralGradAcc<D> acc;
+  acc.init(lds);
+  const size_t row = (size_t)a.nn.B * D;
+  const size_t poff = (size_t)L.p * D;
+  v4 lam_y = splat4(0.f), lam_f = splat4(0.f);
+  float sig_d = 0.f;
+  v4 a1[HT];
+
+  for (int n = a.n_acc - 1; n >= 0; --n) {
+    const double t0 = a.tape_t[n], dt = a.tape_dt[n];
+    const double t1 = t0 + dt;
+    const float t0f = (float)t0, dtf = (float)dt, t1f = (float)t1;
+    const bool first = n == 0;
+    const float rdt = div_f32(1.0f, dtf);
+    float sd = 0.f;
+    v4 k[7], Ys[7];
+    float dose[7];
+    Ys[0] = mf_load_rows<D>(a.tape_y + (size_t)n * row + poff, g);
+    dose[0] = neural_dose(a.nn, L.p, L.dosage, first ? a.nn.t[0] : nextafter_down(t0f));
+    k[0] = nn.rhs(mf_with_dose<D>(Ys[0], dose[0], g), a1);
+#pragma unroll
+    for (int i = 2; i <= 7; ++i) {
+      v4 Y = Ys[0];
+#pragma unroll
+      for (int m = 0; m < i - 1; ++m) Y = vfma4(kDpBeta[i - 2][m] * dtf, k[m], Y);
+      Ys[i - 1] = Y;
+      dose[i - 1] = neural_dose(a.nn, L.p, L.dosage, dp_stage_time(i, t0f, dtf, t1f));
+      k[i - 1] = nn.rhs(mf_with_dose<D>(Y, dose[i - 1], g), a1);
+    }
+
+    v4 gk[7], lam_y0 = splat4(0.f), lam_mid = splat4(0.f);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) gk[m] = splat4(0.f);
+    gk[6] = lam_f;
+    const int jlo = a.tape_j[2 * n], jhi = a.tape_j[2 * n + 1];
+    if (jlo < jhi) {
+      // p'(x) / dt from the stage derivatives (the y0 terms of the quartic's coefficients cancel exactly), see dp_bwd_body
+      v4 s1 = splat4(0.f), sm = splat4(0.f);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) s1 = vfma4(kDpBeta[5][m], k[m], s1);
+#pragma unroll
+      for (int m = 0; m < 7; ++m) sm = vfma4(kDpMid[m], k[m], sm);
+      const v4 ca = 4.0f * (2.0f * (k[6] - k[0]) - 8.0f * s1 + 16.0f * sm);
+      const v4 cb = 3.0f * ((5.0f * k[0] - 3.0f * k[6]) + 14.0f * s1 - 32.0f * sm);
+      const v4 cc = 2.0f * ((k[6] - 4.0f * k[0]) - 5.0f * s1 + 16.0f * sm);
+      for (int j = jlo; j < jhi; ++j) {
+        const float x = (float)(((double)a.nn.t[j] - t0) / (t1 - t0));
+        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+        const float P0 = 1.0f - 11.0f * x2 + 18.0f * x3 - 8.0f * x4;
+        const float P1 = -5.0f * x2 + 14.0f * x3 - 8.0f * x4;
+        const float Pm = 16.0f * x2 - 32.0f * x3 + 16.0f * x4;
+        const float Q0 = dtf * (x - 4.0f * x2 + 5.0f * x3 - 2.0f * x4);
+        const float Q1 = dtf * (x2 - 3.0f * x3 + 2.0f * x4);
+        const v4 G = L.lv * mf_load_rows<D>(a.nn.grad_h + (size_t)j * row + poff, g);
+        lam_y0 = vfma4(P0, G, lam_y0);
+        lam_y = vfma4(P1, G, lam_y);
+        lam_mid = vfma4(Pm, G, lam_mid);
+        gk[0] = vfma4(Q0, G, gk[0]);
+        gk[6] = vfma4(Q1, G, gk[6]);
+        const v4 dp = ((k[0] + x * cc) + x2 * cb) + x3 * ca;
+        sig_d = __builtin_fmaf(first ? -x : -1.0f, hsum4(G * dp), sig_d);
+      }
+      if (first) {
+        sd += hsum4(gk[0] * k[0]) + hsum4((gk[6] - lam_f) * k[6]);
+        sig_d += hsum4(lam_mid * sm);
+      }
+    }
+    lam_y0 = lam_y0 + lam_mid;
+#pragma unroll
+    for (int m = 0; m < 7; ++m) gk[m] = vfma4(dtf * kDpMid[m], lam_mid, gk[m]);
+    // stage 7: k7 = f(t1-, y1)
+    v4 av = ndp_vjp<D>(nn, acc, mf_with_dose<D>(Ys[6], dose[6], g), k[6], gk[6], g, L.n);
+    lam_y = lam_y + av;
+    lam_y0 = lam_y0 + lam_y;
+    if (first) sd += hsum4(lam_y * (Ys[6] - Ys[0]));
+#pragma unroll
+    for (int m = 0; m < 6; ++m) gk[m] = vfma4(kDpBeta[5][m] * dtf, lam_y, gk[m]);
+#pragma unroll
+    for (int st = 6; st >= 2; --st) {
+      av = ndp_vjp<D>(nn, acc, mf_with_dose<D>(Ys[st - 1], dose[st - 1], g), k[st - 1], gk[st - 1], g, L.n);
+      lam_y0 = lam_y0 + av;
+      if (first) sd += hsum4(av * (Ys[st - 1] - Ys[0]));
+#pragma unroll
+      for (int m = 0; m < st - 1; ++m) gk[m] = vfma4(kDpBeta[st - 2][m] * dtf, av, gk[m]);
+    }
+    if (first) {
+      av = ndp_vjp<D>(nn, acc, mf_with_dose<D>(Ys[0], dose[0], g), k[0], gk[0], g, L.n);
+      lam_y0 = lam_y0 + av;
+    }
+    lam_y = lam_y0;
+    lam_f = gk[0];
+    sig_d = __builtin_fmaf(sd, rdt, sig_d);
+  }
+  lam_y = lam_y + L.lv * mf_load_rows<D>(a.nn.grad_h + poff, g);
+  mf_store_rows<D>(a.nn.grad_y0 + poff, g, lam_y, L.live);
+  const float sig = wave_sum(sig_d);  // rows >= D and dead patients carry zero cotangents
+  if (L.lane == 0) a.partials[L.wave] = sig;
+  acc.store(a.grad_partials + (size_t)L.wave * NeuralGradAcc<D>::NP, L.lane);
+}
+
+// ------------------------------------------------------------------------------- backward of the initial step size
+// dp_initbwd_body for this rhs (no stage-time term).  PASS 1: the batch-global part of the cotangent of h0;
+// PASS 2: everything into grad_y0 and a second block of weight-gradient partials.
+template <int D, int PASS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ndp_initbwd_kernel(NdpArgs a) {
+  constexpr int HT = NeuralMf<D>::HT;
+  __shared__ __attribute__((aligned(16))) float lds[NeuralGradAcc<D>::kLdsFloats];
+  const NdpLane<D> L(a);
+  const int g = L.g;
+  const DpInit in = *a.init;
+  const float sigma = fold_waves(a.partials, a.n_waves, 1, 0);
+  float* gout = a.grad_partials + (size_t)L.wave * NeuralGradAcc<D>::NP;
+  if (!in.first_accepted || sigma == 0.0f) {
+    if constexpr (PASS == 1) {
+      if (L.lane == 0) a.partials[a.n_waves + L.wave] = 0.f;
+    } else {
+      NeuralGradAcc<D>::store_zero(gout, L.lane);
+      if (L.wave == 0 && L.lane == 0) a.init->sigma = in.first_accepted ? sigma : 0.f;
+    }
+    return;
+  }
+  NeuralMf<D> nn;
+  nn.load(a.nn, L.lane);
+  NeuralGradAcc<D> acc;
+  acc.init(lds);
+  const size_t poff = (size_t)L.p * D;
+  const float NN = (float)a.nn.B * (float)D;
+  const float h0 = in.h0, d0 = in.d0, d1 = in.d1, d2 = in.d2, h1 = in.h1;
+  const bool deg0 = d0 < 1e-5f || d1 < 1e-5f;
+  const bool deg1 = d1 <= 1e-15f && d2 <= 1e-15f;
+  const bool use_d2 = d2 > d1;
+  const bool branch_a = 100.0f * h0 <= h1;
+  float h0b = branch_a ? 100.0f * sigma : 0.0f;
+  const float h1b = branch_a ? 0.0f : sigma;
+  float d1b = 0.f, d2b = 0.f;
+  if (deg1) {
+    if (h0 * 1e-3f > 1e-6f) h0b = __builtin_fmaf(1e-3f, h1b, h0b);
+  } else {
+    const float mb = -0.2f * div_f32(h1, use_d2 ? d2 : d1) * h1b;
+    if (use_d2) d2b = mb; else d1b = mb;
+  }
+  const float r2 = d2 * h0;
+  float r2b = 0.f;
+  if (d2b != 0.0f && r2 > 0.0f) {
+    r2b = div_f32(d2b, h0);
+    h0b -= div_f32(d2b * d2, h0);
+  }
+  v4 a1[HT];
+  const v4 y = mf_load_rows<D>(a.nn.y0 + poff, g);
+  const float t0f = a.nn.t[0];
+  const v4 e0 = mf_with_dose<D>(y, neural_dose(a.nn, L.p, L.dosage, t0f), g);
+  const v4 f0 = nn.rhs(e0, a1);
+  const v4 e1 = mf_with_dose<D>(vfma4(h0, f0, y), neural_dose(a.nn, L.p, L.dosage, add_rn(t0f, h0)), g);
+  const v4 f1 = nn.rhs(e1, a1);
+  const v4 scale = ndp_scale<D>(a, y);
+  const float cw = r2b != 0.0f ? div_f32(r2b, NN * r2) * L.lv : 0.0f;
+  v4 w, wb, f1b;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w[r] = L.valid[r] != 0.0f ? div_f32(f1[r] - f0[r], scale[r]) : 0.0f;
+    wb[r] = cw * w[r];
+    f1b[r] = div_f32(wb[r], scale[r]);
+  }
+  const v4 y1b = ndp_vjp<D>(nn, acc, e1, f1, f1b, g, L.n);
+  if constexpr (PASS == 1) {
+    const float sp = wave_sum(hsum4(y1b * f0));
+    if (L.lane == 0) a.partials[a.n_waves + L.wave] = sp;
+  } else {
+    h0b += fold_waves(a.partials + a.n_waves, a.n_waves, 1, 0);
+    float d0b = 0.f;
+    if (!deg0) {
+      d0b = div_f32(0.01f, d1) * h0b;
+      d1b -= div_f32(h0, d1) * h0b;
+    }
+    const float cv = d1 > 0.0f ? div_f32(d1b, NN * d1) * L.lv : 0.0f;
+    const float cu = d0 > 0.0f ? div_f32(d0b, NN * d0) * L.lv : 0.0f;
+    v4 f0b, yb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float rs = div_f32(1.0f, scale[r]);
+      const float v = f0[r] * rs * L.valid[r], u = y[r] * rs * L.valid[r];
+      const float vb = cv * v, ub = cu * u;
+      f0b[r] = __builtin_fmaf(h0, y1b[r], (vb - wb[r]) * rs);
+      const float sb = -(wb[r] * w[r] + vb * v + ub * u) * rs;
+      const float sgn = y[r] > 0.0f ? 1.0f : (y[r] < 0.0f ? -1.0f : 0.0f);
+      yb[r] = y1b[r] + ub * rs + sb * a.rtol * sgn;
+    }
+    const v4 a0 = ndp_vjp<D>(nn, acc, e0, f0, f0b, g, L.n);
+    const v4 gy = mf_load_rows<D>(a.nn.grad_y0 + poff, g) + yb + a0;
+    mf_store_rows<D>(a.nn.grad_y0 + poff, g, gy, L.live);
+    acc.store(gout, L.lane);
+    if (L.wave == 0 && L.lane == 0) a.init->sigma = sigma;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace {
+
+size_t nd_align(size_t x) { return (x + 255) / 256 * 256; }
+constexpr size_t kNdInitOffset = 128;
+
+struct NdLayout {
+  size_t ctrl, partials, kbuf, tape_t, tape_dt, tape_j, tape_y, grad_partials, total;
+};
+
+template <int D>
+NdLayout nd_layout(const hode_solve_desc* d) {
+  const int nw = (d->batch + 15) / 16;
+  const size_t BD = (size_t)d->batch * D;
+  const size_t S = (size_t)(d->max_steps > 0 ? d->max_steps : 1);
+  NdLayout L;
+  size_t off = 0;
+  L.ctrl = off; off = nd_align(off + kNdInitOffset + sizeof(DpInit));
+  L.partials = off; off = nd_align(off + (size_t)4 * nw * sizeof(float));
+  L.kbuf = off; off = nd_align(off + 7 * BD * sizeof(float));
+  L.tape_t = off; off = nd_align(off + S * sizeof(double));
+  L.tape_dt = off; off = nd_align(off + S * sizeof(double));
+  L.tape_j = off; off = nd_align(off + 2 * S * sizeof(int));
+  L.tape_y = off; off = nd_align(off + ((d->flags & HODE_FLAG_NO_TAPE) ? 2 : S + 1) * BD * sizeof(float));
+  L.grad_partials = off; off = nd_align(off + (size_t)nw * NeuralGradAcc<D>::NP * sizeof(float));
+  L.total = off;
+  return L;
+}
+
+template <int D>
+NdpArgs nd_args(const hode_solve_desc* d, const NdLayout& L) {
+  NdpArgs a{};
+  char* ws = (char*)d->workspace;
+  a.nn.t = d->t; a.nn.y0 = d->y0; a.nn.dosage = d->dosage; a.nn.dose_times = d->dose_times;
+  a.nn.w1 = d->w1; a.nn.b1 = d->b1; a.nn.w2 = d->w2; a.nn.b2 = d->b2; a.nn.w2t = nullptr;
+  a.nn.h = d->h; a.nn.grad_h = d->grad_h; a.nn.grad_y0 = d->grad_y0;
+  a.nn.B = d->batch; a.nn.T = d->n_times; a.nn.K = d->n_dose; a.nn.perturb = 0;
+  a.ctrl = (DpCtrl*)(ws + L.ctrl);
+  a.init = (DpInit*)(ws + L.ctrl + kNdInitOffset);
+  a.partials = (float*)(ws + L.partials);
+  a.kbuf = (float*)(ws + L.kbuf);
+  a.tape_t = (double*)(ws + L.tape_t);
+  a.tape_dt = (double*)(ws + L.tape_dt);
+  a.tape_j = (int*)(ws + L.tape_j);
+  a.tape_y = (float*)(ws + L.tape_y);
+  a.grad_partials = (float*)(ws + L.grad_partials);
+  a.grad_w1 = d->grad_w1; a.grad_b1 = d->grad_b1; a.grad_w2 = d->grad_w2; a.grad_b2 = d->grad_b2;
+  a.n_waves = (d->batch + 15) / 16;
+  a.max_steps = d->max_steps;
+  a.ring = (d->flags & HODE_FLAG_NO_TAPE) ? 1 : 0;
+  a.rtol = (float)d->rtol; a.atol = (float)d->atol;
+  return a;
+}
+
+int nd_next_chunk(int chunk, long long attempts, int j_next, int n_times) {
+  const double done = n_times > 1 ? (double)(j_next - 1) / (double)(n_times - 1) : 1.0;
+  if (done <= 0.0) return chunk * 2 > 1024 ? 1024 : chunk * 2;
+  long long c = (long long)(0.75 * (double)attempts * (1.0 - done) / done);
+  if (c < 16) c = 16;
+  if (c > 1024) c = 1024;
+  return (int)c;
+}
+
+template <int D>
+int nd_fwd(const hode_solve_desc* d, hipStream_t s) {
+  const NdLayout lay = nd_layout<D>(d);
+  if (!d->workspace || d->workspace_bytes < lay.total)
+    return fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, lay.total);
+  NdpArgs a = nd_args<D>(d, lay);
+  const dim3 grid(a.n_waves), block(64);
+  hipLaunchKernelGGL((ndp_fwd_kernel<D, 0>), grid, block, 0, s, a);
+  hipLaunchKernelGGL((ndp_fwd_kernel<D, 1>), grid, block, 0, s, a);
+  if (int e = hip_fail(hipGetLastError(), "neural dopri5 init launch")) return e;
+  DpCtrl host{};
+  int attempt = 0, chunk = 32;
+  const long long max_attempts = 64LL * ((long long)d->max_steps + 64);
+  for (;;) {
+    for (int i = 0; i < chunk; ++i) {
+      a.attempt = attempt++;
+      hipLaunchKernelGGL((ndp_fwd_kernel<D, 2>), grid, block, 0, s, a);
+    }
+    if (int e = hip_fail(hipGetLastError(), "neural dopri5 attempt launch")) return e;
+    // the ONE host synchronisation of the path: the number of adaptive steps is data dependent
+    if (int e = hip_fail(hipMemcpyAsync(&host, a.ctrl + (attempt & 1), sizeof(DpCtrl), hipMemcpyDeviceToHost, s), "controller read-back"))
+      return e;
+    if (int e = hip_fail(hipStreamSynchronize(s), "controller read-back sync")) return e;
+    if (host.done) break;
+    if (attempt > max_attempts) {
+      host.status |= HODE_STATUS_MAX_STEPS;
+      break;
+    }
+    chunk = nd_next_chunk(chunk, attempt, host.j_next, d->n_times);
+  }
+  *d->host_n_accepted = host.n_acc;
+  if (d->host_n_rejected) *d->host_n_rejected = host.n_rej;
+  if (d->status && host.status) {
+    if (int e = hip_fail(hipMemcpyAsync(d->status, &host.status, sizeof(int), hipMemcpyHostToDevice, s), "status write")) return e;
+    if (int e = hip_fail(hipStreamSynchronize(s), "status write sync")) return e;
+  }
+  return 0;
+}
+
+template <int D>
+int nd_bwd(const hode_solve_desc* d, hipStream_t s) {
+  const NdLayout lay = nd_layout<D>(d);
+  if (!d->workspace || d->workspace_bytes < lay.total)
+    return fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, lay.total);
+  NdpArgs a = nd_args<D>(d, lay);
+  a.n_acc = *d->host_n_accepted;
+  if (a.n_acc < 0 || a.n_acc > d->max_steps) return fail(HODE_E_SIZE, "n_accepted %d outside the tape", a.n_acc);
+  const dim3 grid(a.n_waves), block(64);
+  const dim3 fgrid(NeuralGradAcc<D>::NP);
+  hipLaunchKernelGGL((ndp_bwd_kernel<D>), grid, block, 0, s, a);
+  hipLaunchKernelGGL((ndp_fold_kernel<D>), fgrid, block, 0, s, a.grad_partials, a.n_waves, a.grad_w1, a.grad_b1, a.grad_w2, a.grad_b2);
+  if (a.n_acc > 0 && !(d->flags & HODE_FLAG_DETACH_FIRST_STEP)) {
+    hipLaunchKernelGGL((ndp_initbwd_kernel<D, 1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ndp_initbwd_kernel<D, 2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ndp_fold_kernel<D>), fgrid, block, 0, s, a.grad_partials, a.n_waves, a.grad_w1, a.grad_b1, a.grad_w2, a.grad_b2);
+  }
+  return hip_fail(hipGetLastError(), "neural dopri5 backward launch");
+}
+
+}  // namespace
+
+size_t neural_dopri5_workspace_bytes(const hode_solve_desc* d) {
+  switch (d->latent_dim) {
+    case 6: return nd_layout<6>(d).total;
+    case 8: return nd_layout<8>(d).total;
+    case 12: return nd_layout<12>(d).total;
+  }
+  return 0;
+}
+
+int neural_dopri5_tape_offsets(const hode_solve_desc* d, size_t* out5) {
+  NdLayout L;
+  switch (d->latent_dim) {
+    case 6: L = nd_layout<6>(d); break;
+    case 8: L = nd_layout<8>(d); break;
+    case 12: L = nd_layout<12>(d); break;
+    default: return fail(HODE_E_UNSUPPORTED, "neural dopri5: latent_dim %d has no compiled kernel (have 6, 8, 12)", d->latent_dim);
+  }
+  out5[0] = L.ctrl + kNdInitOffset; out5[1] = L.tape_t; out5[2] = L.tape_dt; out5[3] = L.tape_j; out5[4] = L.tape_y;
+  return 0;
+}
+
+int neural_dopri5(const hode_solve_desc* d, bool bwd, hipStream_t s) {
+  if (d->hidden_dim != 10 * d->latent_dim)
+    return fail(HODE_E_UNSUPPORTED, "neural dopri5: hidden_dim %d != 10 * latent_dim (model.py:992)", d->hidden_dim);
+  if (!d->w1 || !d->b1 || !d->w2 || !d->b2) return fail(HODE_E_NULL, "neural dopri5: w1 / b1 / w2 / b2 required");
+  switch (d->latent_dim) {
+    case 6: return bwd ? nd_bwd<6>(d, s) : nd_fwd<6>(d, s);
+    case 8: return bwd ? nd_bwd<8>(d, s) : nd_fwd<8>(d, s);
+    case 12: return bwd ? nd_bwd<12>(d, s) : nd_fwd<12>(d, s);
+  }
+  return fail(HODE_E_UNSUPPORTED, "neural dopri5: latent_dim %d has no compiled kernel (have 6, 8, 12)", d->latent_dim);
+}
+
+}  // namespace hode

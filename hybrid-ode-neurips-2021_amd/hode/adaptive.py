@@ -151,3 +151,95 @@ def roche_dopri5(y0, theta, w, b, t, dosage, dose_times, rtol=1e-7, atol=1e-9, a
         dose_times = dose_times.reshape(y0.shape[0], -1)
     return _RocheDopri5.apply(y0, theta, w, b, t, dosage, dose_times.to(torch.float32), rtol, atol, bool(ablate),
                               int(lanes_per_patient), int(max_steps), bool(detach_first_step))
+
+
+class _NeuralDopri5(torch.autograd.Function):
+    """NeuralODE rhs (reference model.py:969-1026) through ``hode_dopri5_fwd / _bwd`` with ``HODE_RHS_NEURAL``: the MFMA
+    attempt kernels of csrc/hode_neural_dopri5.hip; the backward accumulates the weight gradients on chip."""
+
+    @staticmethod
+    def forward(ctx, y0, w1, b1, w2, b2, t, dosage, dose_times, rtol, atol, max_steps, detach_first_step):
+        _require_gpu(y0, w1, t, dosage, dose_times)
+        lib = L.lib()
+        B, D = y0.shape
+        T = t.numel()
+        y0c, tc, dosc, dtc = _f32c(y0), _f32c(t), _f32c(dosage), _f32c(dose_times)
+        w1c, b1c, w2c, b2c = _f32c(w1), _f32c(b1), _f32c(w2), _f32c(b2)
+        h = torch.empty((T, B, D), device=y0.device, dtype=torch.float32)
+        no_tape = not any(ctx.needs_input_grad[:5])
+        steps = int(max_steps) if max_steps else ((1 << 20) if no_tape else 16 * T + 64)
+        while True:
+            status = torch.zeros(1, device=y0.device, dtype=torch.int32)
+            n_acc, n_rej = C.c_int32(0), C.c_int32(0)
+            d = L.new_solve_desc()
+            d.rhs_kind = L.RHS_NEURAL
+            d.batch, d.latent_dim, d.n_times, d.hidden_dim = B, D, T, w1c.shape[0]
+            d.n_dose = dtc.shape[1] if dtc.dim() == 2 else 0
+            d.t, d.y0, d.dosage, d.dose_times = tc.data_ptr(), y0c.data_ptr(), dosc.data_ptr(), _ptr(dtc)
+            d.w1, d.b1, d.w2, d.b2 = w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr()
+            d.h, d.status = h.data_ptr(), status.data_ptr()
+            d.rtol, d.atol, d.max_steps = float(rtol), float(atol), steps
+            d.flags = L.FLAG_NO_TAPE if no_tape else 0
+            d.host_n_accepted, d.host_n_rejected = C.pointer(n_acc), C.pointer(n_rej)
+            nbytes = lib.hode_workspace_bytes(d, L.WS_DOPRI5_FWD)
+            free, _ = torch.cuda.mem_get_info(y0.device)
+            if nbytes > free + torch.cuda.memory_reserved(y0.device) - torch.cuda.memory_allocated(y0.device):
+                raise L.HodeError("hode dopri5: a tape of %d accepted steps needs %.1f GB, the device has %.1f GB free "
+                                  "(max_num_steps exceeded)" % (steps, nbytes / 1e9, free / 1e9))
+            ws = torch.empty(nbytes, device=y0.device, dtype=torch.uint8)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+            with torch.cuda.device(y0.device):
+                L.check(lib.hode_dopri5_fwd(d, _stream()), "hode_dopri5_fwd[neural]")
+            st = int(status.item())
+            if st & L.STATUS_MAX_STEPS and not (st & (L.STATUS_NONFINITE | L.STATUS_DT_UNDERFLOW)) and steps < (1 << 20):
+                del ws
+                steps *= 4
+                continue
+            break
+        last_stats.update(n_accepted=n_acc.value, n_rejected=n_rej.value)
+        if st:
+            raise L.HodeError("hode dopri5: " + (_status_error(st) or "max_num_steps exceeded"))
+        ctx.save_for_backward(h, tc, dosc, dtc, y0c, w1c, b1c, w2c, b2c, ws)
+        ctx.meta = (float(rtol), float(atol), steps, n_acc.value, bool(detach_first_step))
+        if keep_workspace:
+            global _last_ws
+            _last_ws = (ws, d, n_acc.value)
+        return h
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        h, tc, dosc, dtc, y0c, w1c, b1c, w2c, b2c, ws = ctx.saved_tensors
+        rtol, atol, steps, n_accepted, detach_first = ctx.meta
+        lib = L.lib()
+        T, B, D = h.shape
+        gh = grad_h.to(torch.float32).contiguous()
+        gy0 = torch.empty((B, D), device=h.device, dtype=torch.float32)
+        gw1, gb1, gw2, gb2 = (torch.zeros_like(x) for x in (w1c, b1c, w2c, b2c))
+        n_acc = C.c_int32(n_accepted)
+        d = L.new_solve_desc()
+        d.rhs_kind = L.RHS_NEURAL
+        d.batch, d.latent_dim, d.n_times, d.hidden_dim = B, D, T, w1c.shape[0]
+        d.n_dose = dtc.shape[1] if dtc.dim() == 2 else 0
+        d.t, d.y0, d.dosage, d.dose_times = tc.data_ptr(), y0c.data_ptr(), dosc.data_ptr(), _ptr(dtc)
+        d.w1, d.b1, d.w2, d.b2, d.h = w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), h.data_ptr()
+        d.grad_h, d.grad_y0 = gh.data_ptr(), gy0.data_ptr()
+        d.grad_w1, d.grad_b1, d.grad_w2, d.grad_b2 = gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr()
+        d.rtol, d.atol, d.max_steps = rtol, atol, steps
+        d.flags = L.FLAG_DETACH_FIRST_STEP if detach_first else 0
+        d.host_n_accepted = C.pointer(n_acc)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        with torch.cuda.device(h.device):
+            L.check(lib.hode_dopri5_bwd(d, _stream()), "hode_dopri5_bwd[neural]")
+        return gy0, gw1, gb1, gw2, gb2, None, None, None, None, None, None, None
+
+
+#: latent dimensions the fused neural dopri5 kernels are compiled for (csrc/hode_neural_dopri5.hip)
+NEURAL_DIMS = (6, 8, 12)
+
+
+def neural_dopri5(y0, w1, b1, w2, b2, t, dosage, dose_times, rtol=1e-7, atol=1e-9, max_steps=0, detach_first_step=False):
+    """Adaptive solve of dy/dt = tanh(W2 tanh(W1 [y, Dose(t)] + b1) + b2); returns h (T, B, D)."""
+    if dose_times.dim() != 2:
+        dose_times = dose_times.reshape(y0.shape[0], -1)
+    return _NeuralDopri5.apply(y0, w1, b1, w2, b2, t, dosage, dose_times.to(torch.float32), rtol, atol, int(max_steps),
+                               bool(detach_first_step))

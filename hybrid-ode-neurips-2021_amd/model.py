@@ -225,6 +225,11 @@ class NeuralODE(nn.Module):
             raise RuntimeError("NeuralODE: call set_action(a) before integrating")
         from hode import neural
         if method == "dopri5":
+            from hode import adaptive
+            if self.latent_dim in adaptive.NEURAL_DIMS and y0.is_cuda:
+                # the reference's default for --method=neural (sim_config.py:50): fused MFMA attempt kernels
+                return adaptive.neural_dopri5(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight,
+                                              self.ml_net[2].bias, t, self.dosage, self.times, rtol=rtol, atol=atol)
             return _eager_dopri5(self, y0, t, rtol, atol, options)
         from hode import substep
         perturb = bool(options.pop("perturb", False))
@@ -238,7 +243,7 @@ _EAGER_DOPRI5_ANNOUNCED = set()
 
 
 def _eager_dopri5(ode, y0, t, rtol, atol, options):
-    """(NeuralODE, "dopri5"): no fused adaptive kernel exists for this right-hand side.  The solve runs
+    """(NeuralODE, "dopri5") at a latent dimension the fused kernels are not compiled for (they cover 6, 8, 12).  The solve runs
     as torch GPU launches per stage (``hode.adaptive_eager``: torchdiffeq's dopri5 semantics, discrete adjoint over the
     accepted-step tape) -- said once per rhs class, never silently, and never on the CPU."""
     from hode import adaptive_eager

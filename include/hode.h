@@ -271,7 +271,9 @@ int hode_rk_fwd(const hode_solve_desc* desc, void* hip_stream);
 int hode_rk_bwd(const hode_solve_desc* desc, void* hip_stream);
 
 /* adaptive Dormand-Prince 5(4), torchdiffeq 0.2.2 semantics (batch-global controller, dense output).
- * Synchronises the stream once per chunk of attempts to read the controller record. */
+ * Synchronises the stream once per chunk of attempts to read the controller record.
+ * rhs kinds: HODE_RHS_ROCHE / _ABLATE (latent_dim 4, 6, 8, 12) and HODE_RHS_NEURAL (latent_dim 6, 8, 12, hidden_dim = 10 D;
+ * the backward accumulates into grad_w1 [10D][D+1], grad_b1 [10D], grad_w2 [D][10D], grad_b2 [D] -- no operand tape). */
 int hode_dopri5_fwd(const hode_solve_desc* desc, void* hip_stream);
 int hode_dopri5_bwd(const hode_solve_desc* desc, void* hip_stream);
 

@@ -171,3 +171,28 @@ def test_odeint_step_size_option_sub_steps_like_torchdiffeq(roche, step_size):
         if po.grad is None or float(po.grad.abs().max()) < 1e-12:
             continue
         assert _rel(p.grad, po.grad) <= 2e-3, (n, _rel(p.grad, po.grad))
+
+
+def test_training_and_evaluation_run_from_device_resident_folds(tmp_path, capsys):
+    """hode.batches.DeviceFolds behind the mirrored loops: every batch is produced on the device (one
+    gather per field, contiguous), the training loop, evaluate and evaluate_horizon consume it unchanged."""
+    import training_utils
+    from hode import synth
+    from hode.batches import DeviceFolds
+    dev = _dev()
+    T, obs, D = 16, 40, 8
+    folds = DeviceFolds.synthetic(192, T, obs, D, 32, 32, dev, seed=4)
+    b = folds.get_mini_batch("train", 64)
+    assert all(v.is_cuda and v.is_contiguous() and v.shape[1] == 64 for v in b.values())
+    torch.manual_seed(1)
+    enc = model.EncoderLSTM(obs + 1, obs * 2, D, device=dev)
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * synth.STEP, synth.STEP, method="rk4", device=dev)
+    vi = model.VariationalInference(enc, dec, prior_log_pdf=model.ExponentialPrior.log_density)
+    opt = torch.optim.Adam(list(enc.parameters()) + list(dec.output_function.parameters()) + list(dec.ode.ml_net.parameters()), lr=1e-3)
+    w0 = dec.ode.ml_net[0].weight.detach().clone()
+    vi, best, _ = training_utils.variational_training_loop(4, folds, vi, 64, opt, 2, path=str(tmp_path) + "/")
+    assert best < 1e9 and not torch.equal(dec.ode.ml_net[0].weight.detach(), w0)
+    out = training_utils.evaluate(vi, folds, 16, 8, mc_itr=5)
+    assert len(out) == 6 and all(v == v for v in out)
+    hz = training_utils.evaluate_horizon(vi, folds, 16, 8, mc_itr=3)
+    assert hz["rmse_x"].shape == (T - 8,)
