@@ -52,6 +52,7 @@ size_t neural_workspace_bytes(const hode_solve_desc* d, bool bwd);
 int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
 struct NeuralArgs;
 int launch_neural_mf(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s);  // hode_neural_mf.hip
+size_t neural_mf_partial_bytes(const hode_solve_desc* d);
 
 // adaptive solve of the neural rhs on the matrix cores (hode_neural_dopri5.hip)
 size_t neural_dopri5_workspace_bytes(const hode_solve_desc* d);

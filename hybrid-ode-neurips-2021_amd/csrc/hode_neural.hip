@@ -268,12 +268,25 @@ struct NeuralLayout {
   size_t w2t, a1t, u1t, yet, u2t, total;
 };
 
+// the matrix-core backward accumulates the weight gradients on chip when the caller hands it the accumulators (grad_w1 set);
+// HODE_NEURAL_LAYOUT=t (lane-per-patient kernels) and callers without accumulators get the operand tapes
+bool neural_onchip(const hode_solve_desc* d) {
+  const char* env = getenv("HODE_NEURAL_LAYOUT");
+  return !(env && env[0] == 't') && d->grad_w1 != nullptr;
+}
+
 NeuralLayout neural_layout(const hode_solve_desc* d, bool bwd) {
   const size_t D = d->latent_dim, HD = 10 * D, B = d->batch;
   const size_t inst = (size_t)(d->n_times > 0 ? d->n_times - 1 : 0) * n_stages(d->method);
   NeuralLayout L;
   size_t off = 0;
   L.w2t = off; off = al256(off + HD * D * 4);
+  if (bwd && neural_onchip(d)) {  // one block of gradient partials per wave in the a1t slot, no tapes
+    L.a1t = off; off = al256(off + hode::neural_mf_partial_bytes(d));
+    L.u1t = L.yet = L.u2t = off;
+    L.total = off;
+    return L;
+  }
   L.a1t = off; if (bwd) off = al256(off + inst * HD * B * 4);
   L.u1t = off; if (bwd) off = al256(off + inst * HD * B * 4);
   L.yet = off; if (bwd) off = al256(off + inst * (D + 1) * B * 4);
@@ -293,6 +306,8 @@ int check_neural(const hode_solve_desc* d, bool bwd) {
   if (!d->t || !d->y0 || !d->dosage || !d->h || !d->w1 || !d->b1 || !d->w2 || !d->b2 || (d->n_dose > 0 && !d->dose_times))
     return hode::fail(HODE_E_NULL, "t / y0 / dosage / dose_times / h / w1 / b1 / w2 / b2 must be non-NULL");
   if (bwd && (!d->grad_h || !d->grad_y0)) return hode::fail(HODE_E_NULL, "grad_h / grad_y0 required by the backward");
+  if (bwd && d->grad_w1 && (!d->grad_b1 || !d->grad_w2 || !d->grad_b2))
+    return hode::fail(HODE_E_NULL, "grad_w1 given: grad_b1 / grad_w2 / grad_b2 are required too (on-chip weight gradients)");
   const NeuralLayout L = neural_layout(d, bwd);
   if (!d->workspace || d->workspace_bytes < L.total)
     return hode::fail(HODE_E_WORKSPACE, "workspace %zu B < required %zu B", d->workspace_bytes, L.total);
@@ -355,6 +370,8 @@ int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s) {
 
 extern "C" int hode_neural_tape_offsets(const hode_solve_desc* d, size_t* out4) {
   if (!d || !out4 || d->struct_size != sizeof(hode_solve_desc)) return hode::fail(HODE_E_NULL, "descriptor / out4");
+  if (neural_onchip(d))
+    return hode::fail(HODE_E_UNSUPPORTED, "grad_w1 is set: the backward accumulates the weight gradients itself, there are no tapes");
   hode::neural_tape_offsets(d, out4);
   return 0;
 }

@@ -19,7 +19,7 @@
 // and stage -- the pre-activation cotangents and the layer inputs are transposed through two LDS images (patient-major) so
 // that the patient index becomes the MFMA contraction index, and the wave keeps dW1 | db1 (a ones row appended to the
 // layer-1 input) and dW2 in 2 x HT accumulator tiles for the whole sweep.  One partial block per wave, folded in a fixed
-// order by ndp_fold_kernel (deterministic; no operand tape in HBM, no host GEMM).
+// order by neural_grad_fold_kernel (deterministic; no operand tape in HBM, no host GEMM).
 #include <hip/hip_runtime.h>
 
 #include "hode_dopri5_kernels.hpp"
@@ -47,21 +47,6 @@ struct NdpArgs {
 };
 
 HODE_DEV size_t ndp_tape_row(const NdpArgs& a, int n) { return (size_t)(a.ring ? (n & 1) : n); }
-HODE_DEV v4 splat4(float x) { return v4{x, x, x, x}; }
-HODE_DEV float hsum4(const v4& v) { return (v[0] + v[1]) + (v[2] + v[3]); }
-HODE_DEV v4 vfma4(float a, const v4& b, const v4& c) {
-  v4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(a, b[i], c[i]);
-  return r;
-}
-HODE_DEV v4 vfma4(const v4& a, const v4& b, const v4& c) {
-  v4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(a[i], b[i], c[i]);
-  return r;
-}
-
 // per-lane context: which patient / rows this lane holds
 template <int D>
 struct NdpLane {
@@ -277,110 +262,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       cout->n_acc = c.n_acc; cout->n_rej = c.n_rej; cout->j_next = c.j_next; cout->done = c.done; cout->attempt = c.attempt;
       if (c.status) atomicOr(&cout->status, c.status);
     }
-  }
-}
-
-// ------------------------------------------------------------------------------ weight gradients on the matrix cores
-// dW1[h][i] += sum_n u1[h][n] e[i][n]  (i = D + 1 is a ones row: the column that collects db1),
-// dW2[o][h] += sum_n u2[o][n] a1[h][n],  db2[o] += sum_n u2[o][n]  over the wave's 16 patients n, per stage VJP.
-// The register tiles hold [row][patient] with the patient in (lane & 15), which is the MFMA's B layout with the ROW as the
-// contraction index; the outer products contract over PATIENTS, so the four operands go through LDS patient-major
-// (16-byte stores: a lane's four rows are consecutive) and come back with lane (m, kk) reading image[4c + kk][.. + m]:
-// A[m][kk] / B[kk][m] fragments of patient chunk c.  72 ds_read_b32 + 18 ds_write_b128 + 64 MFMAs per stage.
-template <int D>
-struct NeuralGradAcc {
-  static constexpr int HT = NeuralMf<D>::HT;
-  // image pitches (floats) == 16 mod 64: the fragment read of lane (m, kk) at [4c + kk][16i + m] then hits bank m + 16 kk
-  // -- all 64 lanes on different banks -- and the 16-byte writes of lane (g, n) at [n][16i + 4g] spread 4 dwords per bank
-  static constexpr int PH = ((16 * HT - 16 + 63) / 64) * 64 + 16;
-  static constexpr int PS = 16;
-  static constexpr int kLdsFloats = 16 * (2 * PH + 2 * PS);
-  static constexpr int NP = 2 * HT * 256 + 16;  // floats per wave in the partial array
-  static constexpr int GB = (D + 1) / 4, RB = (D + 1) % 4;  // tile position of the ones row behind [y, Dose]
-  v4 dW1[HT], dW2[HT], db2;
-  float *U1, *A1, *E, *U2;
-
-  HODE_DEV void init(float* lds) {
-    U1 = lds;
-    A1 = lds + 16 * PH;
-    E = lds + 32 * PH;
-    U2 = E + 16 * PS;
-#pragma unroll
-    for (int i = 0; i < HT; ++i) dW1[i] = dW2[i] = splat4(0.f);
-    db2 = splat4(0.f);
-  }
-  HODE_DEV void add(const v4 (&u1)[HT], v4 e, const v4& u2, const v4 (&a1)[HT], int g, int n) {
-    if (g == GB) e[RB] = 1.0f;
-    __syncthreads();  // the previous call's reads are done
-#pragma unroll
-    for (int i = 0; i < HT; ++i) {
-      *reinterpret_cast<v4*>(U1 + n * PH + 16 * i + 4 * g) = u1[i];
-      *reinterpret_cast<v4*>(A1 + n * PH + 16 * i + 4 * g) = a1[i];
-    }
-    *reinterpret_cast<v4*>(E + n * PS + 4 * g) = e;
-    *reinterpret_cast<v4*>(U2 + n * PS + 4 * g) = u2;
-    __syncthreads();
-    const int m = n, kk = g;  // fragment coordinates of this lane
-    float eB[4], u2A[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      eB[c] = E[(4 * c + kk) * PS + m];
-      u2A[c] = U2[(4 * c + kk) * PS + m];
-    }
-#pragma unroll
-    for (int i = 0; i < HT; ++i) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float au = U1[(4 * c + kk) * PH + 16 * i + m];
-        const float ba = A1[(4 * c + kk) * PH + 16 * i + m];
-        dW1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(au, eB[c], dW1[i], 0, 0, 0);
-        dW2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(u2A[c], ba, dW2[i], 0, 0, 0);
-      }
-    }
-    db2 = db2 + u2;
-  }
-  // one block of NP floats per wave: [dW1 tiles | dW2 tiles] as [tile][lane][4], then db2[16]
-  HODE_DEV void store(float* __restrict__ out, int lane) {
-#pragma unroll
-    for (int i = 0; i < HT; ++i) {
-      *reinterpret_cast<v4*>(out + ((size_t)i * 64 + lane) * 4) = dW1[i];
-      *reinterpret_cast<v4*>(out + ((size_t)(HT + i) * 64 + lane) * 4) = dW2[i];
-    }
-    v4 s;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = row_sum(db2[r]);  // over the 16 patients of this row group
-    if ((lane & 15) == 0) *reinterpret_cast<v4*>(out + 2 * HT * 256 + 4 * (lane >> 4)) = s;
-  }
-  HODE_DEV static void store_zero(float* __restrict__ out, int lane) {
-    for (int i = lane; i < NP; i += 64) out[i] = 0.f;
-  }
-};
-
-// fixed-order fold of the per-wave blocks into the caller's accumulators (one wave per slot of the block)
-template <int D>
-__global__ __launch_bounds__(64) void ndp_fold_kernel(const float* __restrict__ partials, int n_waves, float* __restrict__ gw1,
-                                                      float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2) {
-  constexpr int HD = 10 * D, HT = NeuralMf<D>::HT, NP = NeuralGradAcc<D>::NP;
-  const int j = blockIdx.x, lane = threadIdx.x;
-  float s = 0.f;
-  for (int w = lane; w < n_waves; w += 64) s += partials[(size_t)w * NP + j];
-  s = wave_sum(s);
-  if (lane != 0) return;
-  if (j >= 2 * HT * 256) {
-    const int o = j - 2 * HT * 256;
-    if (o < D && gb2) gb2[o] += s;
-    return;
-  }
-  const int tile = j / 256, l = (j % 256) / 4, r = j % 4;
-  const int rw = 4 * (l >> 4) + r, col = l & 15;
-  if (tile < HT) {
-    const int hid = 16 * tile + rw;
-    if (hid >= HD) return;
-    if (col <= D) { if (gw1) gw1[(size_t)hid * (D + 1) + col] += s; }
-    else if (col == D + 1) { if (gb1) gb1[hid] += s; }
-  } else {
-    const int hid = 16 * (tile - HT) + col;
-    if (rw < D && hid < HD && gw2) gw2[(size_t)rw * HD + hid] += s;
   }
 }
 
@@ -713,11 +594,11 @@ int nd_bwd(const hode_solve_desc* d, hipStream_t s) {
   const dim3 grid(a.n_waves), block(64);
   const dim3 fgrid(NeuralGradAcc<D>::NP);
   hipLaunchKernelGGL((ndp_bwd_kernel<D>), grid, block, 0, s, a);
-  hipLaunchKernelGGL((ndp_fold_kernel<D>), fgrid, block, 0, s, a.grad_partials, a.n_waves, a.grad_w1, a.grad_b1, a.grad_w2, a.grad_b2);
+  hipLaunchKernelGGL((neural_grad_fold_kernel<D>), fgrid, block, 0, s, a.grad_partials, a.n_waves, a.grad_w1, a.grad_b1, a.grad_w2, a.grad_b2);
   if (a.n_acc > 0 && !(d->flags & HODE_FLAG_DETACH_FIRST_STEP)) {
     hipLaunchKernelGGL((ndp_initbwd_kernel<D, 1>), grid, block, 0, s, a);
     hipLaunchKernelGGL((ndp_initbwd_kernel<D, 2>), grid, block, 0, s, a);
-    hipLaunchKernelGGL((ndp_fold_kernel<D>), fgrid, block, 0, s, a.grad_partials, a.n_waves, a.grad_w1, a.grad_b1, a.grad_w2, a.grad_b2);
+    hipLaunchKernelGGL((neural_grad_fold_kernel<D>), fgrid, block, 0, s, a.grad_partials, a.n_waves, a.grad_w1, a.grad_b1, a.grad_w2, a.grad_b2);
   }
   return hip_fail(hipGetLastError(), "neural dopri5 backward launch");
 }

@@ -66,10 +66,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
 }
 
-template <int D, int METHOD>
+// ONCHIP: the weight gradients are accumulated by the wave on the matrix cores (NeuralGradAcc, hode_neural_mf.hpp) and
+// leave as one partial block per wave in a.a1t (folded by neural_grad_fold_kernel); otherwise their operands are taped
+// patient-minor for the caller's GEMMs (the contract of hode_neural_tape_offsets, kept for the lane-per-patient kernels).
+template <int D, int METHOD, bool ONCHIP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void neural_mf_bwd_kernel(NeuralArgs a) {
   constexpr int HD = 10 * D;
   constexpr int HT = NeuralMf<D>::HT;
+  __shared__ __attribute__((aligned(16))) float lds[ONCHIP ? NeuralGradAcc<D>::kLdsFloats : 4];
+  NeuralGradAcc<D> acc;
+  if constexpr (ONCHIP) acc.init(lds);
   constexpr int NS = METHOD == HODE_METHOD_EULER ? 1 : (METHOD == HODE_METHOD_MIDPOINT ? 2 : 4);
   const int lane = threadIdx.x;
   NeuralMf<D> nn;
@@ -110,32 +116,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const float dt = st.dt;
     const size_t i0 = (size_t)nstep * NS;
     const v4 y = mf_load_rows<D>(a.h + (size_t)nstep * row + (size_t)p * D, g);
-    v4 e[NS], k[NS], a1[NS][HT];
+    v4 e[NS], k[NS], a1[ONCHIP ? 1 : NS][HT];  // ONCHIP: only the last stage's activations stay, the VJPs recompute theirs
     // ---- recompute the stages (inputs and hidden activations go to the tape as they are formed)
     e[0] = mf_with_dose<D>(y, neural_dose(a, p, dosage, st.t_first), g);
     k[0] = nn.rhs(e[0], a1[0]);
     if constexpr (METHOD == HODE_METHOD_MIDPOINT) {
       e[1] = mf_with_dose<D>(y + (0.5f * dt) * k[0], neural_dose(a, p, dosage, st.ta), g);
-      k[1] = nn.rhs(e[1], a1[1]);
+      k[1] = nn.rhs(e[1], a1[ONCHIP ? 0 : 1]);
     } else if constexpr (METHOD == HODE_METHOD_RK4_38) {
       e[1] = mf_with_dose<D>(y + (dt * k[0]) * kThird, neural_dose(a, p, dosage, st.ta), g);
-      k[1] = nn.rhs(e[1], a1[1]);
+      k[1] = nn.rhs(e[1], a1[ONCHIP ? 0 : 1]);
       e[2] = mf_with_dose<D>(y + dt * (k[1] - k[0] * kThird), neural_dose(a, p, dosage, st.tb), g);
-      k[2] = nn.rhs(e[2], a1[2]);
+      k[2] = nn.rhs(e[2], a1[ONCHIP ? 0 : 2]);
       e[3] = mf_with_dose<D>(y + dt * ((k[0] - k[1]) + k[2]), neural_dose(a, p, dosage, st.t_last), g);
-      k[3] = nn.rhs(e[3], a1[3]);
+      k[3] = nn.rhs(e[3], a1[ONCHIP ? 0 : 3]);
     }
+    if constexpr (!ONCHIP) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      tape_rows(a.yet, i0 + s, D + 1, e[s]);
-      tape_hidden(a.a1t, i0 + s, a1[s]);
+      for (int s = 0; s < NS; ++s) {
+        tape_rows(a.yet, i0 + s, D + 1, e[s]);
+        tape_hidden(a.a1t, i0 + s, a1[s]);
+      }
     }
     // ---- adjoint of the stages
     auto vjp = [&](int s, const v4& gk) {
       v4 u2, u1[HT];
-      v4 av = nn.vjp(a1[s], k[s], gk, u2, u1);
-      tape_rows(a.u2t, i0 + s, D, u2);
-      tape_hidden(a.u1t, i0 + s, u1);
+      if constexpr (ONCHIP) {
+        if (s != NS - 1) nn.hidden(e[s], a1[0]);  // 384 registers of activations would not fit next to the accumulators
+      }
+      v4 av = nn.vjp(a1[ONCHIP ? 0 : s], k[s], gk, u2, u1);
+      if constexpr (ONCHIP) {
+        acc.add(u1, e[s], u2, a1[0], g, nn.n);
+      } else {
+        tape_rows(a.u2t, i0 + s, D, u2);
+        tape_hidden(a.u1t, i0 + s, u1);
+      }
       if (g == NeuralMf<D>::GD) av[NeuralMf<D>::RD] = 0.f;  // the Dose input is not a state
       return av;
     };
@@ -166,20 +181,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     lam = lam + lv * mf_load_rows<D>(a.grad_h + (size_t)nstep * row + (size_t)p * D, g);
   }
   mf_store_rows<D>(a.grad_y0 + (size_t)p * D, g, lam, live);
+  if constexpr (ONCHIP) acc.store(a.a1t + (size_t)blockIdx.x * NeuralGradAcc<D>::NP, lane);
 }
 
 template <int D>
 int launch_neural_mf_d(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s) {
   const dim3 grid((d->batch + 15) / 16), block(64);
+  const bool onchip = bwd && d->grad_w1 != nullptr;
 #define HODE_NEURAL_MF_LAUNCH(M)                                                                   \
-  if (bwd) hipLaunchKernelGGL((neural_mf_bwd_kernel<D, M>), grid, block, 0, s, a);                 \
+  if (bwd && onchip) hipLaunchKernelGGL((neural_mf_bwd_kernel<D, M, true>), grid, block, 0, s, a);  \
+  else if (bwd) hipLaunchKernelGGL((neural_mf_bwd_kernel<D, M, false>), grid, block, 0, s, a);      \
   else hipLaunchKernelGGL((neural_mf_fwd_kernel<D, M>), grid, block, 0, s, a);
   switch (d->method) {
     case HODE_METHOD_EULER: HODE_NEURAL_MF_LAUNCH(HODE_METHOD_EULER) break;
     case HODE_METHOD_MIDPOINT: HODE_NEURAL_MF_LAUNCH(HODE_METHOD_MIDPOINT) break;
     default: HODE_NEURAL_MF_LAUNCH(HODE_METHOD_RK4_38) break;
   }
+  if (onchip)
+    hipLaunchKernelGGL((neural_grad_fold_kernel<D>), dim3(NeuralGradAcc<D>::NP), block, 0, s, a.a1t, (int)grid.x, d->grad_w1,
+                       d->grad_b1, d->grad_w2, d->grad_b2);
   return hip_fail(hipGetLastError(), "neural MFMA kernel launch");
+}
+
+// bytes of per-wave gradient partials the on-chip backward needs (it uses the a1t slot of the workspace for them)
+size_t neural_mf_partial_bytes(const hode_solve_desc* d) {
+  const size_t nw = (d->batch + 15) / 16;
+  switch (d->latent_dim) {
+    case 6: return nw * NeuralGradAcc<6>::NP * sizeof(float);
+    case 8: return nw * NeuralGradAcc<8>::NP * sizeof(float);
+    default: return nw * NeuralGradAcc<12>::NP * sizeof(float);
+  }
 }
 
 int launch_neural_mf(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s) {

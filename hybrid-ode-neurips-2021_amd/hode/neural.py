@@ -1,11 +1,14 @@
 """Fixed-grid solve of the pure neural latent ODE (reference ``NeuralODE``, ``model.py:969-1026``) on the gfx950 kernels.
 
-The backward kernel returns ``grad_y0`` and tapes the operands of the weight-gradient outer products; they are
-contracted here with batched BLAS GEMMs (a GEMM is what a sum of outer products over patients is)."""
+The matrix-core backward kernel returns ``grad_y0`` and accumulates the weight gradients on chip (outer products over the
+wave's patients as MFMAs, one partial block per wave, fixed-order fold).  The one-patient-per-lane kernels
+(``HODE_NEURAL_LAYOUT=t``) tape the operands of those outer products instead and they are contracted here with batched
+BLAS GEMMs."""
 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -56,11 +59,17 @@ class _NeuralFixedGrid(torch.autograd.Function):
         gy0 = torch.empty((B, D), device=h.device, dtype=torch.float32)
         d = _desc(h[0], tc, dosc, dtc, w1c, b1c, w2c, b2c, h, method, perturb)
         d.grad_h, d.grad_y0 = gh.data_ptr(), gy0.data_ptr()
+        onchip = os.environ.get("HODE_NEURAL_LAYOUT", "")[:1] != "t"
+        if onchip:
+            gw1, gb1, gw2, gb2 = (torch.zeros_like(x) for x in (w1c, b1c, w2c, b2c))
+            d.grad_w1, d.grad_b1, d.grad_w2, d.grad_b2 = gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr()
         n = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
         ws = torch.empty(max(n, 4), device=h.device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = ws.data_ptr(), n
         with torch.cuda.device(h.device):
             L.check(lib.hode_rk_bwd(d, _stream()), "hode_rk_bwd[neural]")
+        if onchip:
+            return gy0, gw1, gb1, gw2, gb2, None, None, None, None, None
         off = (C.c_size_t * 4)()
         L.check(lib.hode_neural_tape_offsets(d, off), "hode_neural_tape_offsets")
         inst = (T - 1) * _STAGES[method]

@@ -251,10 +251,13 @@ typedef struct hode_mckl_desc {
 int hode_version(void);
 const char* hode_last_error_string(void);
 
-/* HODE_RHS_NEURAL backward: hode_rk_bwd fills grad_y0 and writes, per (step, stage) instance, the four operands of
- * the weight-gradient GEMMs patient-minor into the workspace: a1t[inst][10D][B], u1t[inst][10D][B], yet[inst][D+1][B],
- * u2t[inst][D][B] (inst = (T-1) * stages).  This returns their byte offsets; the caller contracts them:
- * grad_w1 = sum_inst u1t yet^T, grad_b1 = sum u1t, grad_w2 = sum_inst u2t a1t^T, grad_b2 = sum u2t. */
+/* HODE_RHS_NEURAL backward.  With grad_w1 / grad_b1 / grad_w2 / grad_b2 set (accumulators, [10D][D+1] / [10D] / [D][10D] /
+ * [D]) hode_rk_bwd accumulates the weight gradients itself -- outer products over patients on the matrix cores, one
+ * partial block per wave folded in a fixed order -- and the workspace is a few MB.  With grad_w1 == NULL it fills grad_y0
+ * only and writes, per (step, stage) instance, the four operands of the weight-gradient GEMMs patient-minor into the
+ * workspace: a1t[inst][10D][B], u1t[inst][10D][B], yet[inst][D+1][B], u2t[inst][D][B] (inst = (T-1) * stages); this returns
+ * their byte offsets and the caller contracts them: grad_w1 = sum_inst u1t yet^T, grad_b1 = sum u1t, grad_w2 = sum_inst u2t
+ * a1t^T, grad_b2 = sum u2t (the one-patient-per-lane kernels, HODE_NEURAL_LAYOUT=t, always work this way). */
 int hode_neural_tape_offsets(const hode_solve_desc* desc, size_t* out4);
 
 /* HODE_RHS_ROCHE_REAL backward: hode_rk_bwd fills grad_y0 and grad_theta[0..2] (k_immunity, kel, kel2) and tapes the
