@@ -190,7 +190,7 @@ def pmc_traffic(tape=True):
                 if "split" in k and k.count(",") < 4 and tape:
                     continue
                 best = {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "kernel": k,
-                        "valu_active_frac": v.get("valu_active_frac")}
+                        "valu_active_frac": v.get("valu_active_fraction_of_wave_cycles")}
     return best
 
 

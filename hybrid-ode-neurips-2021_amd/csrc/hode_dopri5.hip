@@ -1,4 +1,5 @@
 // C-ABI entry points hode_dopri5_fwd / hode_dopri5_bwd (include/hode.h): workspace carving, the attempt loop, checks.
+#include <stdlib.h>
 #include <string.h>
 
 #include "hode_dopri5_kernels.hpp"
@@ -14,6 +15,7 @@ using hode::DpLaunch;
 // enqueued past the end costs an early-exit launch (~1.3 us).  The chunk therefore starts small, doubles while nothing is
 // known, and then follows an estimate of what is left: attempts so far scaled by the output-grid progress j_next / T.
 constexpr int kChunkFirst = 64, kChunkMin = 32, kChunkMax = 2048;
+constexpr int kAttemptWavesPerBlock = 1;
 
 int next_chunk(int chunk, long long attempts, int j_next, int n_times) {
   const double done = n_times > 1 ? (double)(j_next - 1) / (double)(n_times - 1) : 1.0;
@@ -163,6 +165,11 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
   L.phase = 1;
   if (int e = dp_dispatch_dim(d, L, a, s)) return e;
   L.phase = 2;
+  L.waves_per_block = kAttemptWavesPerBlock;
+  if (const char* env = getenv("HODE_DP_WPB")) {  // tuning
+    const int v = atoi(env);
+    if (v >= 1 && v <= 4) L.waves_per_block = v;
+  }
   {
     // which rhs specialisation the attempts run (both Hill exponents == 2 is the shipped configuration) is a property of
     // the parameters: read the two exponents back once, under the init kernels, instead of on the device in every launch

@@ -416,7 +416,7 @@ HODE_DEV void dp_attempt_body(const DpArgs& a) {
     bad |= !__builtin_isfinite(y[i]);
   }
   se = wave_sum(se * ((lm.live && lm.q == 0) ? 1.0f : 0.0f));
-  if ((threadIdx.x & 63) == 0) pout[2 * (gid >> 6)] = se;
+  if ((threadIdx.x & 63) == 0 && (gid >> 6) < a.n_waves) pout[2 * (gid >> 6)] = se;
   store_vec<D, LPP>(a.tape_y + dp_tape_row(a, c.n_acc + 1) * row + poff, Y[6], lm.q, lm.live);
 #pragma unroll
   for (int m = 0; m < 7; ++m) store_vec<D, LPP>(a.kbuf + (size_t)m * row + poff, k[m], lm.q, lm.live);
@@ -512,6 +512,17 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
   const size_t row = (size_t)a.B * D;
   const size_t poff = (size_t)lm.p * D;
   const float cnt = (float)a.B * (float)D;
+  // Diagnostics (build with HODE_DP_FLAGS=-DHODE_DP_STAMPS, tools/dp_stamp_probe.py): lane 0 of block 0 and of block
+  // n_waves / 2 stamp s_memtime behind a full s_waitcnt at the waits of the attempt, into the (forward-idle) gradient
+  // partial array.  Measured timeline of an attempt at 10 000 x 12 (2.4 GHz): DESIGN.md section 5.
+#ifdef HODE_DP_STAMPS
+  const bool stamp = a.attempt < 2300 && (threadIdx.x == 0) && (blockIdx.x == 0 || blockIdx.x == (unsigned)a.n_waves / 2);
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.grad_partials) + ((size_t)a.attempt * 2 + (blockIdx.x ? 1 : 0)) * 8;
+#define HODE_STAMP(i) if (stamp) { __builtin_amdgcn_s_waitcnt(0); dbg[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define HODE_STAMP(i)
+#endif
+  HODE_STAMP(0)
   // level 1: everything addressed by the kernel arguments alone is requested before anything is waited for
   const FoldHead head = fold_issue(pin, a.n_waves, 2, 0);
   const RocheTheta th = load_theta(a.theta, ABLATE);
@@ -520,6 +531,7 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
   const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
   const DpCtrl cin = a.ctrl[par];
   __builtin_amdgcn_sched_barrier(0);
+  HODE_STAMP(1)   // level-1 loads back (the stamp waits for everything outstanding)
   if (cin.done) {
     if (gid == 0) *cout = cin;
     return;
@@ -532,6 +544,7 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
   Own::load(a.kbuf + 6 * row + poff, q, k_last);
   const float t_next = a.t[min(cin.j_next, a.T - 1)];
   __builtin_amdgcn_sched_barrier(0);
+  HODE_STAMP(2)   // level-2 loads back
 
   DpCtrl c = cin;
   float y[NO], f0[NO];
@@ -625,6 +638,7 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
     return;
   }
 
+  HODE_STAMP(3)   // decision taken, dense output (if any) written
   // ---- new attempt from (y, f0) at (t0, dt), owned components only
   const float t0f = (float)c.t0, dtf = (float)c.dt, t1f = (float)(c.t0 + c.dt);
   float k[7][NO], Yo[NO];
@@ -655,8 +669,9 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
     se = __builtin_fmaf(u, u, se);
     bad |= !__builtin_isfinite(y[s]);
   }
+  HODE_STAMP(4)   // stages and error estimate done
   se = wave_sum(lm.live ? se : 0.0f);  // every component of every live patient is owned by exactly one lane
-  if ((threadIdx.x & 63) == 0) pout[2 * (gid >> 6)] = se;
+  if ((threadIdx.x & 63) == 0 && (gid >> 6) < a.n_waves) pout[2 * (gid >> 6)] = se;  // the last block may carry idle waves
   Own::store(a.tape_y + dp_tape_row(a, c.n_acc + 1) * row + poff, q, Yo, lm.live);
   Own::store(a.kbuf + poff, q, k[0], lm.live);
   Own::store(a.kbuf + 6 * row + poff, q, k[6], lm.live);
@@ -671,10 +686,14 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
     cout->n_acc = c.n_acc; cout->n_rej = c.n_rej; cout->j_next = c.j_next; cout->done = c.done; cout->attempt = c.attempt;
     if (c.status) atomicOr(&cout->status, c.status);
   }
+  HODE_STAMP(5)   // stores drained
+#undef HODE_STAMP
 }
 
+// PHASE 2 (the attempt) runs as workgroups of up to 4 waves: a launch's fixed cost grows with the number of workgroups the
+// dispatcher has to place, and an attempt is ~6 us long (wave indices, partials and lane maps are per wave either way)
 template <int D, int LPP, bool ABLATE, int PHASE>
-__global__ __launch_bounds__(64) void dp_fwd_kernel(DpArgs a) {
+__global__ __launch_bounds__(PHASE == 2 ? 256 : 64) void dp_fwd_kernel(DpArgs a) {
   const bool hill2 = ABLATE || (a.hill2 >= 0 ? a.hill2 != 0 : (a.theta[0] == 2.0f && a.theta[1] == 2.0f));
 #define HODE_DP_DISPATCH(BODY)                                             \
   if (hill2 && a.K == 1) BODY<D, LPP, ABLATE, true, true>(a);              \
@@ -1326,6 +1345,7 @@ struct DpLaunch {
   int lpp;
   bool ablate, need_th;
   int phase;  // 0 init1, 1 init2, 2 attempt, 3 backward sweep, 4 / 5 initial-step backward pass 1 / 2
+  int waves_per_block = 1;  // attempt launches only (1..4)
 };
 
 template <int D, int LPP, bool ABLATE>
@@ -1334,7 +1354,11 @@ int dp_launch(const DpLaunch& L, const DpArgs& a, hipStream_t s) {
   switch (L.phase) {
     case 0: hipLaunchKernelGGL((dp_fwd_kernel<D, LPP, ABLATE, 0>), grid, block, 0, s, a); break;
     case 1: hipLaunchKernelGGL((dp_fwd_kernel<D, LPP, ABLATE, 1>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((dp_fwd_kernel<D, LPP, ABLATE, 2>), grid, block, 0, s, a); break;
+    case 2: {
+      const int wpb = L.waves_per_block > 0 ? L.waves_per_block : 1;
+      hipLaunchKernelGGL((dp_fwd_kernel<D, LPP, ABLATE, 2>), dim3((a.n_waves + wpb - 1) / wpb), dim3(64 * wpb), 0, s, a);
+      break;
+    }
     case 3:
       if (L.need_th) hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, false>), grid, block, 0, s, a);
