@@ -30,7 +30,7 @@ def units():
         u.append(("hode_rk_d%d" % d, os.path.join(CSRC, "hode_rk_dim.hip"), ["-DHODE_DIM=%d" % d]))
     for d in DP_DIMS:
         u.append(("hode_dp_d%d" % d, os.path.join(CSRC, "hode_dopri5_dim.hip"), ["-DHODE_DIM=%d" % d] + DP_FLAGS))
-    for name in ("hode_dopri5", "hode_lstm", "hode_neural", "hode_real", "hode_rk_mf", "hode_readout", "hode_rk_split", "hode_crps", "hode_mckl", "hode_neural_mf", "hode_real_mf", "hode_neural_dopri5"):
+    for name in ("hode_dopri5", "hode_lstm", "hode_neural", "hode_real", "hode_rk_mf", "hode_readout", "hode_rk_split", "hode_crps", "hode_mckl", "hode_neural_mf", "hode_real_mf", "hode_neural_dopri5", "hode_readout_mlp"):
         src = os.path.join(CSRC, name + ".hip")
         if os.path.exists(src):
             u.append((name, src, EXTRA_FLAGS.get(name, [])))

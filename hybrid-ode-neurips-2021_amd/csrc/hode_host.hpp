@@ -65,6 +65,7 @@ int real_rk(const hode_solve_desc* d, bool bwd, hipStream_t s);
 struct RealArgs;
 bool real_mf_supported(const hode_solve_desc* d);                                              // hode_real_mf.hip
 int launch_real_mf(const hode_solve_desc* d, const RealArgs& a, bool bwd, hipStream_t s);
+size_t real_mf_partial_bytes(const hode_solve_desc* d);
 
 // MFMA-layout Roche kernels (hode_rk_mf.hip)
 bool mf_supported(const hode_solve_desc* d);

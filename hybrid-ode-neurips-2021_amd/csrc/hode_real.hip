@@ -334,12 +334,19 @@ struct RealLayout {
   size_t tape, partials, dose, total;
 };
 // [ tape (bwd) | theta partials (bwd) | dose table (both) ]; the tape stays first: hode/real.py views it from offset 0
+// the matrix-core backward accumulates the weight gradients on chip when the caller hands it the flat accumulator (grad_w1)
+bool real_onchip(const hode_solve_desc* d) {
+  const char* env = getenv("HODE_REAL_LAYOUT");
+  return hode::real_mf_supported(d) && !(env && env[0] == 't') && d->grad_w1 != nullptr;
+}
+
 RealLayout real_layout(const hode_solve_desc* d, bool bwd) {
   RealLayout L{0, 0, 0, 0};
   size_t off = 0;
   if (bwd) {
     const size_t inst = (size_t)(d->n_times - 1) * real_stages(d->method);
-    L.tape = off; off = ral256(off + inst * real_rows(d) * (size_t)d->batch * 4);
+    L.tape = off;
+    off = ral256(off + (real_onchip(d) ? hode::real_mf_partial_bytes(d) : inst * real_rows(d) * (size_t)d->batch * 4));
     L.partials = off; off = ral256(off + (size_t)((d->batch + 15) / 16) * 3 * 4);  // one row per wave of either layout
   }
   L.dose = off; off = ral256(off + (size_t)2 * (d->n_action_times + 1) * (size_t)d->batch * 4);

@@ -189,7 +189,130 @@ struct RealMf {
   }
 };
 
-template <int HT, int METHOD, bool BWD>
+// ------------------------------------------------------------------------------ weight gradients on the matrix cores
+// The eleven weight gradients of the rhs are outer products summed over patients (recipe of NeuralGradAcc in
+// hode_neural_mf.hpp: operands transposed through patient-major LDS images so that the patient index becomes the MFMA
+// contraction index).  Per stage VJP, over the wave's 16 patients:
+//   dWa[i] += U1 tile i (x) [X | 1]      i <  HT: rows of dW11 (cols 0..2) and db11 (col 4, the ones row behind X)
+//                                         i >= HT: rows of dW21 (cols 0..1) and db21 (col 4)
+//   dWb[i] += [u12; u22] (x) ah tile i    i <  HT: row 0 = dw12;  i >= HT: row 1 = dw22   (the cross terms are not read)
+//   dHh += uh (x) r*h,  dHz += uz (x) h,  dHr += ur (x) h;   db12 / db22: per-lane sums of u12 / u22
+// 60 MFMAs, 19 ds_write_b128 and 76 ds_read_b32 per stage at HT = 3 instead of ~70 strided tape stores per lane; one block
+// of NP floats per wave, folded in a fixed order by real_grad_fold_kernel into the flat weight-gradient buffer.
+template <int HT>
+struct RealGradAcc {
+  static constexpr int NT2 = 2 * HT;
+  static constexpr int PH = ((16 * NT2 - 16 + 63) / 64) * 64 + 16;  // pitch == 16 mod 64: conflict-free fragment reads
+  static constexpr int kLdsFloats = 2 * 16 * PH + 7 * 256;
+  static constexpr int NP = (2 * NT2 + 3) * 256 + 16;
+  v4 dWa[NT2], dWb[NT2], dHh, dHz, dHr, db2;
+  float *U1i, *AHi, *Xi, *U2i, *UHi, *UZi, *URi, *RHi, *HHi;
+  HODE_DEV void init(float* lds) {
+    U1i = lds; AHi = lds + 16 * PH;
+    float* sm = lds + 32 * PH;
+    Xi = sm; U2i = sm + 256; UHi = sm + 512; UZi = sm + 768; URi = sm + 1024; RHi = sm + 1280; HHi = sm + 1536;
+    const v4 z = v4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NT2; ++i) dWa[i] = dWb[i] = z;
+    dHh = dHz = dHr = db2 = z;
+  }
+  HODE_DEV void add(const v4 (&U1)[NT2], const v4 (&ah)[NT2], v4 X, float u12, float u22, const v4& uh, const v4& uz,
+                    const v4& ur, const v4& rh, const v4& hh, int g, int n) {
+    if (g == 1) X[0] = 1.0f;  // row 4: the bias column
+    const v4 U2 = v4{u12, u22, 0.f, 0.f};  // lanes g > 0 carry zeros (gX is zero there)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NT2; ++i) {
+      *reinterpret_cast<v4*>(U1i + n * PH + 16 * i + 4 * g) = U1[i];
+      *reinterpret_cast<v4*>(AHi + n * PH + 16 * i + 4 * g) = ah[i];
+    }
+    *reinterpret_cast<v4*>(Xi + n * 16 + 4 * g) = X;
+    *reinterpret_cast<v4*>(U2i + n * 16 + 4 * g) = U2;
+    *reinterpret_cast<v4*>(UHi + n * 16 + 4 * g) = uh;
+    *reinterpret_cast<v4*>(UZi + n * 16 + 4 * g) = uz;
+    *reinterpret_cast<v4*>(URi + n * 16 + 4 * g) = ur;
+    *reinterpret_cast<v4*>(RHi + n * 16 + 4 * g) = rh;
+    *reinterpret_cast<v4*>(HHi + n * 16 + 4 * g) = hh;
+    __syncthreads();
+    const int m = n, kk = g;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int o = (4 * c + kk) * 16 + m;
+      const float xB = Xi[o], u2A = U2i[o], rhB = RHi[o], hhB = HHi[o];
+      dHh = mfma4(UHi[o], rhB, dHh);
+      dHz = mfma4(UZi[o], hhB, dHz);
+      dHr = mfma4(URi[o], hhB, dHr);
+#pragma unroll
+      for (int i = 0; i < NT2; ++i) {
+        dWa[i] = mfma4(U1i[(4 * c + kk) * PH + 16 * i + m], xB, dWa[i]);
+        dWb[i] = mfma4(u2A, AHi[(4 * c + kk) * PH + 16 * i + m], dWb[i]);
+      }
+    }
+    db2 = db2 + U2;
+  }
+  HODE_DEV void store(float* __restrict__ out, int lane) {
+#pragma unroll
+    for (int i = 0; i < NT2; ++i) {
+      *reinterpret_cast<v4*>(out + ((size_t)i * 64 + lane) * 4) = dWa[i];
+      *reinterpret_cast<v4*>(out + ((size_t)(NT2 + i) * 64 + lane) * 4) = dWb[i];
+    }
+    *reinterpret_cast<v4*>(out + ((size_t)(2 * NT2) * 64 + lane) * 4) = dHh;
+    *reinterpret_cast<v4*>(out + ((size_t)(2 * NT2 + 1) * 64 + lane) * 4) = dHz;
+    *reinterpret_cast<v4*>(out + ((size_t)(2 * NT2 + 2) * 64 + lane) * 4) = dHr;
+    v4 sv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sv[r] = row_sum(db2[r]);
+    if ((lane & 15) == 0) *reinterpret_cast<v4*>(out + (2 * NT2 + 3) * 256 + 4 * (lane >> 4)) = sv;
+  }
+};
+
+// fixed-order fold of the per-wave blocks into the flat weight gradient (RealW order); one wave per slot of a block
+template <int HT>
+__global__ __launch_bounds__(64) void real_grad_fold_kernel(const float* __restrict__ partials, int n_waves, int H,
+                                                            float* __restrict__ gw) {
+  constexpr int NT2 = 2 * HT, NP = RealGradAcc<HT>::NP, M = 16;
+  const int j = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int w = lane; w < n_waves; w += 64) s += partials[(size_t)w * NP + j];
+  s = wave_sum(s);
+  if (lane != 0) return;
+  const int oW11 = 0, ob11 = 3 * H, ow12 = 4 * H, ob12 = 5 * H, oW21 = 5 * H + 1, ob21 = 7 * H + 1, ow22 = 8 * H + 1,
+            ob22 = 9 * H + 1, oWhh = 9 * H + 2, oWhz = oWhh + M * M, oWhr = oWhz + M * M;
+  if (j >= (2 * NT2 + 3) * 256) {
+    const int o = j - (2 * NT2 + 3) * 256;
+    if (o == 0) gw[ob12] += s;
+    else if (o == 1) gw[ob22] += s;
+    return;
+  }
+  const int tile = j / 256, l = (j % 256) / 4, r = j % 4;
+  const int rw = 4 * (l >> 4) + r, col = l & 15;
+  if (tile < NT2) {
+    const bool first = tile < HT;
+    const int hid = 16 * (first ? tile : tile - HT) + rw;
+    if (hid >= H) return;
+    if (first) {
+      if (col < 3) gw[oW11 + 3 * hid + col] += s;
+      else if (col == 4) gw[ob11 + hid] += s;
+    } else {
+      if (col < 2) gw[oW21 + 2 * hid + col] += s;
+      else if (col == 4) gw[ob21 + hid] += s;
+    }
+  } else if (tile < 2 * NT2) {
+    const int i = tile - NT2;
+    const bool first = i < HT;
+    const int hid = 16 * (first ? i : i - HT) + col;
+    if (hid >= H) return;
+    if (first && rw == 0) gw[ow12 + hid] += s;
+    else if (!first && rw == 1) gw[ow22 + hid] += s;
+  } else {
+    const int which = tile - 2 * NT2;
+    gw[(which == 0 ? oWhh : (which == 1 ? oWhz : oWhr)) + rw * M + col] += s;
+  }
+}
+
+// ONCHIP (backward): weight gradients accumulated by the wave (RealGradAcc), one partial block per wave in a.tape;
+// otherwise the GEMM operands are taped for the caller (contract of the lane-per-patient kernels).
+template <int HT, int METHOD, bool BWD, bool ONCHIP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void real_mf_kernel(RealArgs a) {
   typedef RealMf<HT> Net;
   typedef typename Net::Stage Stage;
@@ -208,6 +331,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const size_t row = B * D;
   const RealTape tl{a.H, M};
   const size_t tstride = (size_t)tl.rows() * B;
+  __shared__ __attribute__((aligned(16))) float lds[(BWD && ONCHIP) ? RealGradAcc<HT>::kLdsFloats : 4];
+  RealGradAcc<HT> acc;
+  if constexpr (BWD && ONCHIP) acc.init(lds);
   if (g0) real_dose_table(a, p, nn.kel);  // each lane reads back only its own column
 
   auto load_state = [&](const float* src, v4& X, v4& Hs) {  // src -> this patient's D floats
@@ -316,6 +442,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         v4 U1[NT2], ur, uz, uh;
         float u12, u22;
         nn.vjp(s[q], gX, gH, aX, aH, U1, u12, u22, ur, uz, uh, dth);
+        if constexpr (ONCHIP) {
+          acc.add(U1, s[q].ah, s[q].X, u12, u22, uh, uz, ur, s[q].RH, s[q].Hs, g, nn.n);
+          return;
+        }
         float* tp = tp0 + (size_t)q * tstride;
         tape_tile(tp, tl.y3(), 3, s[q].X);
         tape_hidden(tp, tl.a11(), s[q].ah);
@@ -372,6 +502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       const float v = wave_sum(g0 ? dth[j] : 0.f);
       if (lane == 0) a.partials[(size_t)blockIdx.x * 3 + j] = v;
     }
+    if constexpr (ONCHIP) acc.store(a.tape + (size_t)blockIdx.x * RealGradAcc<HT>::NP, lane);
   }
 }
 
@@ -382,12 +513,30 @@ bool real_mf_supported(const hode_solve_desc* d) {
 template <int HT, bool BWD>
 int launch_real_mf_ht(const hode_solve_desc* d, const RealArgs& a, hipStream_t s) {
   const dim3 grid((d->batch + 15) / 16), block(64);
+  const bool onchip = BWD && d->grad_w1 != nullptr;
+#define HODE_REAL_MF_LAUNCH(M)                                                                        \
+  if (onchip) hipLaunchKernelGGL((real_mf_kernel<HT, M, BWD, BWD>), grid, block, 0, s, a);              \
+  else hipLaunchKernelGGL((real_mf_kernel<HT, M, BWD, false>), grid, block, 0, s, a);
   switch (d->method) {
-    case HODE_METHOD_EULER: hipLaunchKernelGGL((real_mf_kernel<HT, HODE_METHOD_EULER, BWD>), grid, block, 0, s, a); break;
-    case HODE_METHOD_MIDPOINT: hipLaunchKernelGGL((real_mf_kernel<HT, HODE_METHOD_MIDPOINT, BWD>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((real_mf_kernel<HT, HODE_METHOD_RK4_38, BWD>), grid, block, 0, s, a); break;
+    case HODE_METHOD_EULER: HODE_REAL_MF_LAUNCH(HODE_METHOD_EULER) break;
+    case HODE_METHOD_MIDPOINT: HODE_REAL_MF_LAUNCH(HODE_METHOD_MIDPOINT) break;
+    default: HODE_REAL_MF_LAUNCH(HODE_METHOD_RK4_38) break;
   }
+  if (onchip)
+    hipLaunchKernelGGL((real_grad_fold_kernel<HT>), dim3(RealGradAcc<HT>::NP), block, 0, s, a.tape, (int)grid.x, d->hidden_dim,
+                       d->grad_w1);
   return hip_fail(hipGetLastError(), "real MFMA kernel launch");
+}
+
+// bytes of per-wave gradient partials of the on-chip backward (they take the tape's place in the workspace)
+size_t real_mf_partial_bytes(const hode_solve_desc* d) {
+  const size_t nw = (d->batch + 15) / 16;
+  switch ((d->hidden_dim + 15) / 16) {
+    case 1: return nw * RealGradAcc<1>::NP * sizeof(float);
+    case 2: return nw * RealGradAcc<2>::NP * sizeof(float);
+    case 3: return nw * RealGradAcc<3>::NP * sizeof(float);
+    default: return nw * RealGradAcc<4>::NP * sizeof(float);
+  }
 }
 
 int launch_real_mf(const hode_solve_desc* d, const RealArgs& a, bool bwd, hipStream_t s) {

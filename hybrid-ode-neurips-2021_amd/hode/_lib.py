@@ -86,6 +86,16 @@ class ReadoutDesc(C.Structure):
     ]
 
 
+class ReadoutMlpDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("latent_dim", C.c_int32), ("hidden_dim", C.c_int32), ("obs_dim", C.c_int32),
+        ("batch", C.c_int32), ("scale", C.c_float), ("rows", C.c_int64),
+        ("h", _fp), ("x", _fp), ("mask", _fp), ("time_weight", _fp), ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp),
+        ("lik", _fp), ("grad_h", _fp), ("grad_w1", _fp), ("grad_b1", _fp), ("grad_w2", _fp), ("grad_b2", _fp),
+        ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class CrpsDesc(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("n_times", C.c_int32), ("batch", C.c_int32), ("n_members", C.c_int32),
@@ -117,6 +127,8 @@ EXPORTS = (
     ("hode_dopri5_tape_offsets", C.c_int, (C.POINTER(SolveDesc), C.POINTER(C.c_size_t))),
     ("hode_readout_workspace_bytes", C.c_size_t, (C.POINTER(ReadoutDesc),)),
     ("hode_readout_sse", C.c_int, (C.POINTER(ReadoutDesc), C.c_void_p)),
+    ("hode_readout_mlp_workspace_bytes", C.c_size_t, (C.POINTER(ReadoutMlpDesc),)),
+    ("hode_readout_mlp_sse", C.c_int, (C.POINTER(ReadoutMlpDesc), C.c_void_p)),
     ("hode_ensemble_crps", C.c_int, (C.POINTER(CrpsDesc), C.c_void_p)),
     ("hode_mc_kl_exponential", C.c_int, (C.POINTER(McKlDesc), C.c_void_p)),
     ("hode_lstm_fwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),

@@ -52,3 +52,52 @@ class _ReadoutSSE(torch.autograd.Function):
 def masked_sse_readout(h, x, mask, weight, bias):
     """``sum((x - (h @ weight.T + bias))^2 * mask) / B`` for h (T,B,D), x/mask (T,B,obs); differentiable in h, weight, bias."""
     return _ReadoutSSE.apply(h, x, mask, weight, bias)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# two-layer readout of the real-data decoder (hode_readout_mlp_sse)
+
+def mlp_supported(latent_dim: int, hidden_dim: int, obs_dim: int) -> bool:
+    return latent_dim in (20, 4) and hidden_dim == latent_dim + 1 and obs_dim == 24
+
+
+class _ReadoutMlpSSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, x, mask, w1, b1, w2, b2, time_weight):
+        _require_gpu(h, x, mask, w1, w2)
+        lib = L.lib()
+        T, B, D = h.shape
+        hc, xc, mc = _f32c(h), _f32c(x), _f32c(mask)
+        w1c, b1c, w2c, b2c = _f32c(w1), _f32c(b1), _f32c(w2), _f32c(b2)
+        twc = None if time_weight is None else _f32c(time_weight)
+        need_grad = any(ctx.needs_input_grad)
+        lik = torch.empty(1, device=h.device, dtype=torch.float32)
+        d = L.ReadoutMlpDesc()
+        d.struct_size = L.C.sizeof(L.ReadoutMlpDesc)
+        d.latent_dim, d.hidden_dim, d.obs_dim, d.batch, d.scale, d.rows = D, w1c.shape[0], x.shape[-1], B, 1.0 / B, T * B
+        d.h, d.x, d.mask = hc.data_ptr(), xc.data_ptr(), mc.data_ptr()
+        d.time_weight = 0 if twc is None else twc.data_ptr()
+        d.w1, d.b1, d.w2, d.b2, d.lik = w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), lik.data_ptr()
+        if need_grad:
+            gh = torch.empty_like(hc)
+            gw1, gb1, gw2, gb2 = (torch.zeros_like(t) for t in (w1c, b1c, w2c, b2c))
+            d.grad_h, d.grad_w1, d.grad_b1, d.grad_w2, d.grad_b2 = (t.data_ptr() for t in (gh, gw1, gb1, gw2, gb2))
+        n = lib.hode_readout_mlp_workspace_bytes(d)
+        ws = torch.empty(max(n, 4), device=h.device, dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), n
+        with torch.cuda.device(h.device):
+            L.check(lib.hode_readout_mlp_sse(d, _stream()), "hode_readout_mlp_sse")
+        if need_grad:
+            ctx.save_for_backward(gh, gw1, gb1, gw2, gb2)
+        return lik[0] / B
+
+    @staticmethod
+    def backward(ctx, g):
+        gh, gw1, gb1, gw2, gb2 = ctx.saved_tensors
+        return gh * g, None, None, gw1 * g, gb1 * g, gw2 * g, gb2 * g, None
+
+
+def masked_sse_readout_mlp(h, x, mask, w1, b1, w2, b2, time_weight=None):
+    """``sum((x - (W2 ELU(W1 h + b1) + b2))^2 * mask * time_weight[t]) / B`` for h (T,B,D), x / mask (T,B,obs);
+    differentiable in h and the four parameters (reference model.py:809-813, :859, :1243-1247)."""
+    return _ReadoutMlpSSE.apply(h, x, mask, w1, b1, w2, b2, time_weight)

@@ -6,6 +6,8 @@ the flat weight buffer (parameter creation order of the reference)."""
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -55,11 +57,19 @@ class _RealFixedGrid(torch.autograd.Function):
         gth = torch.zeros(L.N_THETA, device=h.device, dtype=torch.float32)
         d = _desc(h[0], tc, ac, thc, wc, h, method, perturb, H)
         d.grad_h, d.grad_y0, d.grad_theta = gh.data_ptr(), gy0.data_ptr(), gth.data_ptr()
+        # matrix-core kernels (D = 20, hidden <= 64): the weight gradients are accumulated on chip into this flat buffer;
+        # the lane-per-patient kernels (HODE_REAL_LAYOUT=t, D = 4) tape the GEMM operands for the contractions below
+        onchip = D == 20 and H <= 64 and os.environ.get("HODE_REAL_LAYOUT", "")[:1] != "t"
+        if onchip:
+            gw = torch.zeros_like(wc)
+            d.grad_w1 = gw.data_ptr()
         n = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
         ws = torch.empty(max(n, 4), device=h.device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = ws.data_ptr(), n
         with torch.cuda.device(h.device):
             L.check(lib.hode_rk_bwd(d, _stream()), "hode_rk_bwd[real]")
+        if onchip:
+            return gy0, gth[:3].clone(), gw, None, None, None, None, None
         inst = (T - 1) * _STAGES[method]
         rows = 5 + 4 * H + 5 * M
         if inst == 0:

@@ -471,10 +471,29 @@ class DecoderReal(nn.Module):
         self.ode.set_action_static(a, s)
         if init.dim() != 2:
             raise hode.HodeConfigError("DecoderReal: per-step initial states (3-D init) are outside the accelerated path")
-        h = self._odeint(self.ode, init, self.t, method=self.method, options=dict(self.options), rtol=self.rtol, atol=self.atol)
+        h = self.latent(init, a, s)
         if h.is_cuda and h.shape[0] * h.shape[1] >= 65536:
             return _tall_mlp(self.output_function, h)[1:], h
         return self.output_function(h)[1:], h
+
+    def latent(self, init, a, s):
+        """Latent trajectory h (T - t0 + 1, B, D) only (row 0 = the state at t0 - 1, which the readout drops)."""
+        self.ode.set_action_static(a, s)
+        if init.dim() != 2:
+            raise hode.HodeConfigError("DecoderReal: per-step initial states (3-D init) are outside the accelerated path")
+        return self._odeint(self.ode, init, self.t, method=self.method, options=dict(self.options), rtol=self.rtol, atol=self.atol)
+
+    def fused_likelihood_ok(self, x):
+        from hode import readout
+        return (x.is_cuda and self._odeint is hode.odeint
+                and readout.mlp_supported(self.latent_dim, self.output_function[0].out_features, self.obs_dim))
+
+    def masked_sse(self, h, x, mask, time_weight=None):
+        """sum((x - output_function(h[1:]))^2 * mask * time_weight) / B in one fused pass over the rows (x_hat never hits
+        HBM; the two Linear layers, the ELU, the loss and all their gradients are one kernel)."""
+        from hode import readout
+        l0, l2 = self.output_function[0], self.output_function[2]
+        return readout.masked_sse_readout_mlp(h[1:], x, mask, l0.weight, l0.bias, l2.weight, l2.bias, time_weight)
 
 
 class VariationalInference:
@@ -530,6 +549,8 @@ class VariationalInference:
         if getattr(self, "_x_hat", None) is None and getattr(self, "h_hat", None) is not None:
             with torch.no_grad():
                 self._x_hat = self.decoder.output_function(self.h_hat)
+                if isinstance(self.decoder, DecoderReal):
+                    self._x_hat = self._x_hat[1:]  # output_function(h)[1:], model.py:859
         return self._x_hat
 
     @x_hat.setter
@@ -565,13 +586,22 @@ class VariationalInferenceReal(VariationalInference):
         a_in = torch.cat([a, s], dim=-1)
         mu, log_var = self.encoder(x[:t0], a_in[:t0], mask[:t0])
         z = self.encoder.reparameterize(mu, log_var) if self.elbo else mu
-        x_hat, h_hat = self.decoder(z, a, s)
-        self.x_hat, self.h_hat, self.z = x_hat, h_hat, z
-        if self.weight:
-            weight = 1 / torch.arange(1, self.decoder.t_max - t0 + 1, device=x.device)[:, None, None]
+        self.z = z
+        fused = getattr(self.decoder, "fused_likelihood_ok", None)
+        if self.fuse_likelihood and fused is not None and fused(x):
+            # readout MLP + masked, time-weighted SSE (+ every gradient) in one pass; x_hat only if somebody reads vi.x_hat
+            h_hat = self.decoder.latent(z, a, s)
+            self.h_hat, self._x_hat = h_hat, None
+            tw = 1 / torch.arange(1, self.decoder.t_max - t0 + 1, device=x.device, dtype=torch.float32) if self.weight else None
+            lik = self.decoder.masked_sse(h_hat, x[t0:], mask[t0:], tw)
         else:
-            weight = 1.0
-        lik = torch.sum((x[t0:] - x_hat) ** 2 * mask[t0:] * weight) / x[t0:].shape[1]
+            x_hat, h_hat = self.decoder(z, a, s)
+            self.x_hat, self.h_hat = x_hat, h_hat
+            if self.weight:
+                weight = 1 / torch.arange(1, self.decoder.t_max - t0 + 1, device=x.device)[:, None, None]
+            else:
+                weight = 1.0
+            lik = torch.sum((x[t0:] - x_hat) ** 2 * mask[t0:] * weight) / x[t0:].shape[1]
         if not self.elbo:
             return lik
         if self.prior_log_pdf is None:

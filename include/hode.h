@@ -204,6 +204,37 @@ typedef struct hode_readout_desc {
   size_t workspace_bytes;
 } hode_readout_desc;
 
+/* Fused two-layer readout + masked, optionally time-weighted SSE of the real-data model: x_hat = W2 ELU(W1 h + b1) + b2
+ * (DecoderReal.output_function, reference model.py:809-813, applied at :859) and
+ * lik = sum((x - x_hat)^2 * mask * weight[t]) (VariationalInferenceReal.loss, model.py:1243-1247), plus every gradient,
+ * in one pass over the rows on the matrix cores; x_hat is never written.  Compiled for latent_dim in {20, 4},
+ * hidden_dim = latent_dim + 1, obs_dim = 24 (the DDW schema). */
+typedef struct hode_readout_mlp_desc {
+  uint32_t struct_size;
+  int32_t latent_dim;    /* D */
+  int32_t hidden_dim;    /* D + 1 */
+  int32_t obs_dim;       /* 24 */
+  int32_t batch;         /* B: rows are (t, b) time-major, t = row / B indexes time_weight */
+  float scale;           /* 1 / B: folded into the gradients (lik itself is returned as the plain weighted sum) */
+  int64_t rows;          /* T' * B */
+  const float* h;        /* [rows][D] */
+  const float* x;        /* [rows][obs] */
+  const float* mask;     /* [rows][obs] */
+  const float* time_weight; /* [T'] or NULL (weight = 1; model.py:1243-1246) */
+  const float* w1;       /* output_function.0.weight [D+1][D] */
+  const float* b1;       /* [D+1] */
+  const float* w2;       /* output_function.2.weight [obs][D+1] */
+  const float* b2;       /* [obs] */
+  float* lik;            /* out [1] */
+  float* grad_h;         /* out [rows][D] or NULL for the loss only: d(scale * lik)/dh */
+  float* grad_w1;        /* acc, with grad_h */
+  float* grad_b1;        /* acc */
+  float* grad_w2;        /* acc */
+  float* grad_b2;        /* acc */
+  void* workspace;       /* >= hode_readout_mlp_workspace_bytes */
+  size_t workspace_bytes;
+} hode_readout_mlp_desc;
+
 /* Ensemble CRPS of posterior samples (reference training_utils.py:147-176 / :247-264: mc_itr decoder passes stacked to
  * (T', B, obs, M) and properscoring.crps_ensemble per element).  Member m of (time t, patient b) is the latent_dim-vector
  * at h + t * time_stride + m * member_stride + b * patient_stride (floats); with w != NULL the scored value of component
@@ -294,6 +325,9 @@ int hode_dopri5_tape_offsets(const hode_solve_desc* desc, size_t* out5);
 
 size_t hode_readout_workspace_bytes(const hode_readout_desc* desc);
 int hode_readout_sse(const hode_readout_desc* desc, void* hip_stream);
+
+size_t hode_readout_mlp_workspace_bytes(const hode_readout_mlp_desc* desc);
+int hode_readout_mlp_sse(const hode_readout_mlp_desc* desc, void* hip_stream);
 
 /* CRPS = 1/M sum_m |x_m - y| - 1/M^2 sum_{i<j} |x_i - x_j| per scored element; one workgroup per (time, patient) */
 int hode_ensemble_crps(const hode_crps_desc* desc, void* hip_stream);

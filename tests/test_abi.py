@@ -42,16 +42,17 @@ def test_header_functions_are_exported_and_bound(lib):
 def test_struct_sizes_match_the_c_header(tmp_path):
     from hode import _lib as L
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(hode_solve_desc), '
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(hode_solve_desc), '
                    'sizeof(hode_lstm_desc), offsetof(hode_solve_desc, workspace), sizeof(hode_readout_desc), '
-                   'sizeof(hode_crps_desc), offsetof(hode_crps_desc, truth), sizeof(hode_mckl_desc));return 0;}\n' % HEADER)
+                   'sizeof(hode_crps_desc), offsetof(hode_crps_desc, truth), sizeof(hode_mckl_desc), sizeof(hode_readout_mlp_desc), '
+                   'sizeof(hode_dopri5_init_record));return 0;}\n' % HEADER)
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", str(src), "-o", str(exe)])
-    a, b, c, r, k, ko, mk = (int(v) for v in subprocess.check_output([str(exe)]).split())
+    a, b, c, r, k, ko, mk, rm, ir = (int(v) for v in subprocess.check_output([str(exe)]).split())
     assert ctypes.sizeof(L.SolveDesc) == a and ctypes.sizeof(L.LstmDesc) == b
     assert L.SolveDesc.workspace.offset == c
     assert ctypes.sizeof(L.ReadoutDesc) == r and ctypes.sizeof(L.CrpsDesc) == k and L.CrpsDesc.truth.offset == ko
-    assert ctypes.sizeof(L.McKlDesc) == mk
+    assert ctypes.sizeof(L.McKlDesc) == mk and ctypes.sizeof(L.ReadoutMlpDesc) == rm and ctypes.sizeof(L.Dopri5InitRecord) == ir
 
 
 def test_argument_errors_do_not_launch(lib):

@@ -60,3 +60,72 @@ def test_vi_loss_uses_fused_path_and_matches_unfused():
     assert len(g1) == len(g2)
     for a, b in zip(g1, g2):
         assert float((a - b).norm() / (b.norm() + 1e-20)) <= 2e-4
+
+
+@pytest.mark.parametrize("D,T,B,weighted", [(20, 7, 33, False), (20, 5, 100, True), (4, 6, 17, True), (20, 96, 257, False), (20, 1, 1, False)])
+def test_mlp_readout_loss_and_gradients(D, T, B, weighted):
+    """hode_readout_mlp_sse (DecoderReal's Linear(D, D+1) -> ELU -> Linear(D+1, 24) readout fused with the masked,
+    optionally time-weighted SSE of VariationalInferenceReal.loss, reference model.py:809-813 / :859 / :1243-1247) against
+    the plain torch expression in float64; row counts that are not multiples of the 16-row tile, D = 4 (expert-only)."""
+    from hode.readout import masked_sse_readout_mlp
+    dev = _dev()
+    obs = 24
+    gen = torch.Generator().manual_seed(D + B)
+    torch.manual_seed(D + T)
+    h = torch.randn(T, B, D, generator=gen)
+    x = torch.randn(T, B, obs, generator=gen)
+    m = (torch.rand(T, B, obs, generator=gen) < 0.5).float()
+    net = torch.nn.Sequential(torch.nn.Linear(D, D + 1), torch.nn.ELU(), torch.nn.Linear(D + 1, obs))
+    tw = 1 / torch.arange(1, T + 1, dtype=torch.float32) if weighted else None
+    net64 = torch.nn.Sequential(torch.nn.Linear(D, D + 1), torch.nn.ELU(), torch.nn.Linear(D + 1, obs)).double()
+    net64.load_state_dict(net.state_dict())
+    hr = h.clone().double().requires_grad_(True)
+    wref = tw.double()[:, None, None] if weighted else 1.0
+    ref = torch.sum((x.double() - net64(hr)) ** 2 * m.double() * wref) / B
+    (ref * 1.3).backward()
+    hg = h.to(dev).requires_grad_(True)
+    prm = [p.detach().clone().to(dev).requires_grad_(True) for p in (net[0].weight, net[0].bias, net[2].weight, net[2].bias)]
+    lik = masked_sse_readout_mlp(hg, x.to(dev), m.to(dev), *prm, None if tw is None else tw.to(dev))
+    (lik * 1.3).backward()
+    assert abs(lik.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    wants = (hr.grad, net64[0].weight.grad, net64[0].bias.grad, net64[2].weight.grad, net64[2].bias.grad)
+    for got, want in zip([hg.grad] + [p.grad for p in prm], wants):
+        rel = float((got.cpu().double() - want).norm() / want.norm())
+        assert rel <= 3e-5, rel
+    # loss only (no gradient requested): same value, nothing else touched
+    with torch.no_grad():
+        lik2 = masked_sse_readout_mlp(h.to(dev), x.to(dev), m.to(dev), *[p.detach() for p in prm], None if tw is None else tw.to(dev))
+    assert abs(lik2.item() - lik.item()) <= 1e-6 * abs(lik.item())
+
+
+def test_real_vi_loss_uses_fused_mlp_readout_and_matches_unfused():
+    import model
+    dev = _dev()
+    obs, act, stat, D, T, t0, B = 24, 1, 11, 20, 40, 24, 70
+    input_dim = obs + act + stat + 1
+    torch.manual_seed(3)
+    enc = model.EncoderLSTMReal(input_dim, int(input_dim * 1.2), D, output_all=False, reverse=False, device=dev)
+    dec = model.DecoderReal(obs, D, act, stat, int((obs + act + stat) * 1.2), T, 1, method="midpoint", ode_step_size=1.0, ode_type="hybrid", t0=t0, device=dev)
+    gen = torch.Generator().manual_seed(4)
+    data = {k: v.to(dev) for k, v in {
+        "measurements": torch.randn(T, B, obs, generator=gen),
+        "actions": (torch.rand(T, B, 1, generator=gen) < 0.1).float() * torch.rand(T, B, 1, generator=gen),
+        "masks": (torch.rand(T, B, obs, generator=gen) < 0.5).float(), "statics": torch.rand(T, B, stat, generator=gen)}.items()}
+    for weight in (False, True):
+        vi = model.VariationalInferenceReal(enc, dec, elbo=False, t0=t0, weight=weight)
+        for p in vi.parameters():
+            p.grad = None
+        l1 = vi.loss(data)
+        l1.backward()
+        g1 = [p.grad.clone() for p in vi.parameters() if p.grad is not None]
+        assert vi._x_hat is None and vi.x_hat.shape == (T - t0, B, obs)
+        for p in vi.parameters():
+            p.grad = None
+        vi.fuse_likelihood = False
+        l2 = vi.loss(data)
+        l2.backward()
+        g2 = [p.grad.clone() for p in vi.parameters() if p.grad is not None]
+        assert abs(l1.item() - l2.item()) <= 2e-5 * abs(l2.item())
+        assert len(g1) == len(g2)
+        for a, b in zip(g1, g2):
+            assert float((a - b).norm() / (b.norm() + 1e-20)) <= 3e-4
