@@ -202,3 +202,42 @@ def test_dopri5_fp32_state_fp64_clock_gradients_flow():
             d = torch.zeros(2, 2, dtype=torch.float64); d[i, j] = 1e-6
             g[i, j] = (flow(W + d).sum() - flow(W - d).sum()) / 2e-6
     np.testing.assert_allclose(w.grad.double().numpy(), g.numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_dopri5_tape_replay_is_the_free_running_oracle_on_its_own_tape():
+    """`odeint_dopri5_replay` driven along the tape the free-running oracle itself took: identical outputs and identical
+    gradients (same ops in the same order), including the derivative of the first step size -- and detaching that
+    derivative changes grad_y0 at the 1e-3 .. 1e-2 level on a problem with dose jumps (the size of the term the HIP backward
+    has to reproduce, tests/test_hip_dopri5.py)."""
+    from hode import synth
+    from oracle.rhs import RocheRHS, THETA_NAMES
+    from oracle.solvers import odeint, odeint_dopri5_replay
+    N, T, D = 8, 12, 8
+    inp = synth.solver_inputs(N, T, D, seed=5)
+    torch.manual_seed(5)
+    f = RocheRHS(D, synth.STEP)
+    with torch.no_grad():
+        f.ml_net[0].weight.mul_(2.0)
+    f.set_action(inp["actions"])
+    cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(3))
+
+    def grads(h, y0):
+        f.zero_grad()
+        (h * cot).sum().backward()
+        return [y0.grad.clone(), f.ml_net[0].weight.grad.clone(), torch.stack([getattr(f, n).grad for n in THETA_NAMES])]
+
+    y0 = inp["z0"].clone().requires_grad_(True)
+    st = {}
+    h = odeint(f, y0, inp["t"], method="dopri5", rtol=1e-7, atol=1e-8, stats=st)
+    g_full = grads(h, y0)
+    assert st["first_attempt_accepted"] and st["n_rejected"] > st["n_accepted"] > T
+    y0b = inp["z0"].clone().requires_grad_(True)
+    hb = odeint_dopri5_replay(f, y0b, inp["t"], 1e-7, 1e-8, st["tape"], True)
+    g_rep = grads(hb, y0b)
+    assert torch.equal(h.detach(), hb.detach())
+    for a, b in zip(g_rep, g_full):
+        assert torch.equal(a, b)
+    y0c = inp["z0"].clone().requires_grad_(True)
+    g_det = grads(odeint_dopri5_replay(f, y0c, inp["t"], 1e-7, 1e-8, st["tape"], False), y0c)
+    rel = float((g_det[0] - g_full[0]).norm() / g_full[0].norm())
+    assert 1e-3 < rel < 5e-2, rel
