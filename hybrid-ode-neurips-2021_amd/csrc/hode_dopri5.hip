@@ -48,7 +48,7 @@ int dp_n_waves(const hode_solve_desc* d) {
 }
 
 struct DpLayout {
-  size_t ctrl, partials, kbuf, tape_t, tape_dt, tape_j, tape_y, grad_partials, total;
+  size_t ctrl, partials, slots, kbuf, tape_t, tape_dt, tape_j, tape_y, grad_partials, total;
 };
 
 DpLayout dp_layout(const hode_solve_desc* d) {
@@ -59,6 +59,7 @@ DpLayout dp_layout(const hode_solve_desc* d) {
   size_t off = 0;
   L.ctrl = off; off = align_up(off + kInitOffset + sizeof(hode::DpInit));  // two controller records + the DpInit record
   L.partials = off; off = align_up(off + (size_t)4 * nw * sizeof(float));
+  L.slots = off; off = align_up(off + (size_t)2 * nw * sizeof(unsigned long long));
   L.kbuf = off; off = align_up(off + 7 * BD * sizeof(float));
   L.tape_t = off; off = align_up(off + S * sizeof(double));
   L.tape_dt = off; off = align_up(off + S * sizeof(double));
@@ -77,6 +78,7 @@ DpArgs dp_args(const hode_solve_desc* d, const DpLayout& L) {
   a.ctrl = (DpCtrl*)(ws + L.ctrl);
   a.init = (hode::DpInit*)(ws + L.ctrl + kInitOffset);
   a.partials = (float*)(ws + L.partials);
+  a.slots = (unsigned long long*)(ws + L.slots);
   a.kbuf = (float*)(ws + L.kbuf);
   a.tape_t = (double*)(ws + L.tape_t);
   a.tape_dt = (double*)(ws + L.tape_dt);
@@ -182,8 +184,35 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
   int attempt = 0;
   // every attempt either accepts (<= max_steps of those) or shrinks dt by >= 5x towards underflow: a generous bound
   const long long max_attempts = 64LL * ((long long)d->max_steps + 64);
+  // Opt-in (HODE_DP_PERSIST=1, quad layout): the whole attempt loop in one persistent launch (dp_persist_body_own: state in
+  // registers, one hop through memory per attempt instead of a kernel boundary).  Correct and bounded, but MEASURED SLOWER on
+  // this part -- 7.0 us per attempt against 5.7 (tools/dp_persist_probe.py): a fence-free, atomics-free all-to-all exchange
+  // across 8 XCDs still costs ~5 us, more than the ~3.8 us the kernel boundary costs.  Kept as the
+  // reproducible form of that measurement; a launch that cannot assemble its waves falls back to the loop below.
+  bool persist = false;
+  if (const char* env = getenv("HODE_DP_PERSIST")) persist = atoi(env) != 0 && L.lpp == 4 && a.n_waves <= hode::kDpMaxPersistWaves;
+  if (persist) {
+    if (int e = hode::hip_fail(hipMemsetAsync(a.slots, 0, (size_t)2 * a.n_waves * sizeof(unsigned long long), s), "slot clear")) return e;
+    L.phase = 6;
+    a.max_iters = (int)(max_attempts > 0x3fffffff ? 0x3fffffff : max_attempts);
+    if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+    if (int e = hode::hip_fail(hipMemcpyAsync(&host, a.ctrl, sizeof(DpCtrl), hipMemcpyDeviceToHost, s), "controller read-back")) return e;
+    if (int e = hode::hip_fail(hipStreamSynchronize(s), "controller read-back sync")) return e;
+    if (!(host.status & hode::kDpStatusBarrierTimeout)) {
+      if (!host.done) host.status |= HODE_STATUS_MAX_STEPS;
+    } else {
+      // the grid could not assemble (another kernel held the CUs): start over, one launch per attempt
+      persist = false;
+      L.phase = 0;
+      if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+      L.phase = 1;
+      if (int e = dp_dispatch_dim(d, L, a, s)) return e;
+      host = DpCtrl{};
+    }
+  }
+  L.phase = 2;
   int chunk = kChunkFirst;
-  for (;;) {
+  while (!persist) {
     for (int i = 0; i < chunk; ++i) {
       a.attempt = attempt++;
       if (int e = dp_dispatch_dim(d, L, a, s)) return e;

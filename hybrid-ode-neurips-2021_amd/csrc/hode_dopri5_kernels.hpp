@@ -51,6 +51,8 @@ struct DpArgs {
   DpCtrl* ctrl;            // [2]
   DpInit* init;            // [1]
   float* partials;         // [2][2 * n_waves]
+  unsigned long long* slots;  // [2][n_waves]: (sequence number << 32 | error-norm partial) of the persistent attempt loop
+  int max_iters;           // persistent attempt loop: attempts this launch may run
   float* kbuf;             // [7][B][D]
   double* tape_t;          // [max_steps]
   double* tape_dt;         // [max_steps]
@@ -688,6 +690,203 @@ HODE_DEV void dp_attempt_body_own(const DpArgs& a) {
   }
   HODE_STAMP(5)   // stores drained
 #undef HODE_STAMP
+}
+
+// ------------------------------------------------------------------------- persistent attempt loop (owner layout)
+// The whole attempt loop in ONE launch.  An attempt launched on its own spends ~3.8 of its 5.7 us outside the arithmetic
+// (kernel boundary, three dependent cold round trips, store drain -- DESIGN.md 5c); here the state, the stage derivatives,
+// the weights and the controller stay in registers across attempts and the kernel boundary is replaced by ONE hop through
+// memory: every wave publishes (attempt number, error-norm partial) as a single 8-byte agent-scope store into its own
+// slot -- payload and flag are the same word, so there is nothing to order -- and then polls all slots with agent-scope
+// loads until they carry the current attempt number.  No read-modify-write atomics (round 1's arrival counter serialised
+// 625 of them at the memory side), no cache-wide fences.  The partials are summed in fold_waves' order; every wave takes the
+// same decision from the same sum, so the controller needs no exchange at all.
+// MEASURED (tools/dp_persist_probe.py, 10 000 x 12): 7.0 us per attempt against 5.7 for one launch per attempt -- the
+// all-to-all poll across 8 XCDs costs ~5 us, more than the kernel boundary it replaces.  Opt-in (HODE_DP_PERSIST=1).
+// Liveness: all blocks must be resident (625 one-wave blocks on an otherwise idle chip are); the poll is bounded -- a wave
+// that does not see its peers within kDpSpinLimit rounds raises kDpStatusBarrierTimeout and leaves, and so does every
+// other wave (they wait for each other), so the grid always drains; the host then repeats the solve on the
+// launch-per-attempt path.
+constexpr int kDpStatusBarrierTimeout = 8;   // internal status bit, never handed to the caller
+constexpr int kDpSpinLimit = 200000;
+constexpr int kDpMaxPersistWaves = 1024;     // 16 slots per lane
+
+HODE_DEV void dp_slot_publish(unsigned long long* slot, int seq, float v) {
+  const unsigned long long w = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+  __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all n_waves partials of attempt `seq`, summed in fold_waves' order; false when the bounded poll gives up
+HODE_DEV bool dp_slot_gather(const unsigned long long* slots, int n_waves, int seq, float& sum) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long v[16];
+  for (int spin = 0;; ++spin) {
+    // all 16 loads of a round in flight together (indices past the array clamped: a conditional per load would serialise
+    // sixteen cross-XCD round trips)
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      v[j] = __hip_atomic_load(slots + min(lane + 64 * j, n_waves - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool all_here = true;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) all_here &= (int)(v[j] >> 32) == seq;
+    if (__builtin_amdgcn_ballot_w64(!all_here) == 0) break;
+    if (spin >= kDpSpinLimit) return false;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += (lane + 64 * j < n_waves) ? __builtin_bit_cast(float, (unsigned)(v[j] & 0xffffffffull)) : 0.f;
+  sum = wave_sum(s);
+  return true;
+}
+
+template <int D, bool ABLATE, bool HILL2, bool K1>
+HODE_DEV void dp_persist_body_own(const DpArgs& a) {
+  using Own = DpOwn<D>;
+  constexpr int NO = Own::NO;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wave = gid >> 6;
+  const LaneMap<4> lm(a.B, a.ppw);
+  const int q = lm.q;
+  const size_t row = (size_t)a.B * D;
+  const size_t poff = (size_t)lm.p * D;
+  const float cnt = (float)a.B * (float)D;
+  const RocheTheta th = load_theta(a.theta, ABLATE);
+  MlSlice<D, 4> ml;
+  ml.load(a.w1, a.b1, q);
+  const DoseSched<K1> ds = dp_load_dose<K1>(a, lm.p);
+  DpCtrl c = a.ctrl[0];
+  if (c.done) return;
+  float y[NO], f0[NO];
+  Own::load(a.tape_y + dp_tape_row(a, c.n_acc) * row + poff, q, y);
+  Own::load(a.kbuf + poff, q, f0);
+  if (c.attempt == 0) {
+    // finish the initial step selection (order 4): d2 from the partials init2 left, h1, dt_0
+    const float d2 = div_f32(__builtin_sqrtf(fold_waves(a.partials + (size_t)2 * a.n_waves, a.n_waves, 2, 0) / cnt), c.h0);
+    float h1;
+    if (c.d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, c.h0 * 1e-3f);
+    else h1 = powf(div_f32(0.01f, fmaxf(c.d1, d2)), 0.2f);
+    c.dt = (double)fminf(100.0f * c.h0, h1);
+    if (gid == 0) { a.init->d2 = d2; a.init->h1 = h1; }
+    c.attempt = 1;
+  }
+  // termination checks before the first attempt of this launch (same order as the launch-per-attempt kernel)
+  auto stop_now = [&]() {
+    if (c.status) { c.done = 1; return true; }
+    if (c.j_next >= a.T) { c.done = 1; return true; }
+    if (!(c.t0 + c.dt > c.t0)) { c.status |= HODE_STATUS_DT_UNDERFLOW; c.done = 1; return true; }
+    if (c.n_acc >= a.max_steps) { c.status |= HODE_STATUS_MAX_STEPS; c.done = 1; return true; }
+    return false;
+  };
+  bool stopped = stop_now();
+  for (int it = 0; !stopped && it < a.max_iters; ++it) {
+    // ---- attempt number c.attempt from (y, f0) at (t0, dt), owned components only
+    const float t0f = (float)c.t0, dtf = (float)c.dt, t1f = (float)(c.t0 + c.dt);
+    float k[7][NO], Yo[NO];
+#pragma unroll
+    for (int s = 0; s < NO; ++s) k[0][s] = f0[s];
+#pragma unroll
+    for (int i = 2; i <= 7; ++i) {
+      const float ti = dp_stage_time(i, t0f, dtf, t1f);
+#pragma unroll
+      for (int s = 0; s < NO; ++s) {
+        float acc = y[s];
+#pragma unroll
+        for (int m = 0; m < i - 1; ++m) acc = __builtin_fmaf(kDpBeta[i - 2][m] * dtf, k[m][s], acc);
+        Yo[s] = acc;
+      }
+      dp_own_rhs<D, ABLATE, HILL2>(th, ml, ds.at(ti, th.kel).v, q, Yo, k[i - 1]);
+    }
+    float se = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < NO; ++s) {
+      float err = 0.f;
+#pragma unroll
+      for (int m = 0; m < 7; ++m) err = __builtin_fmaf(dtf * kDpErr[m], k[m][s], err);
+      const float tol = a.atol + a.rtol * fmaxf(__builtin_fabsf(y[s]), __builtin_fabsf(Yo[s]));
+      const float u = div_f32(err, tol);
+      se = __builtin_fmaf(u, u, se);
+      bad |= !__builtin_isfinite(y[s]);
+    }
+    se = wave_sum(lm.live ? se : 0.0f);
+    if (__builtin_amdgcn_ballot_w64(bad && lm.live) != 0) se = __builtin_nanf("");  // a non-finite state reaches every wave
+    // ---- the one hop: publish, gather
+    const int seq = c.attempt;
+    unsigned long long* sl = a.slots + (size_t)(seq & 1) * a.n_waves;
+    if ((threadIdx.x & 63) == 0) dp_slot_publish(sl + wave, seq, se);
+    float sum;
+    if (!dp_slot_gather(sl, a.n_waves, seq, sum)) {
+      c.status |= kDpStatusBarrierTimeout;
+      c.done = 1;
+      break;
+    }
+    const float ratio = __builtin_sqrtf(sum / cnt);
+    if (!(ratio == ratio)) {  // torchdiffeq asserts on the state before a step; here every wave sees it at once
+      c.status |= HODE_STATUS_NONFINITE;
+      c.done = 1;
+      break;
+    }
+    // ---- decision (every wave computes the same record)
+    const double t1 = c.t0 + c.dt;
+    if (seq == 1 && gid == 0) a.init->first_accepted = ratio <= 1.0f ? 1 : 0;
+    if (ratio <= 1.0f) {
+      int j = c.j_next;
+      if (j < a.T && (double)a.t[j] <= t1) {
+        // quartic dense output of the accepted step on the owned components: everything it needs is in registers
+        float ym[NO], ca[NO], cb[NO], cc_[NO], cd[NO];
+#pragma unroll
+        for (int s = 0; s < NO; ++s) {
+          ym[s] = y[s];
+#pragma unroll
+          for (int m = 0; m < 7; ++m) ym[s] = __builtin_fmaf(dtf * kDpMid[m], k[m][s], ym[s]);
+          const float f0i = k[0][s], f1i = k[6][s], y0i = y[s], y1i = Yo[s], ymi = ym[s];
+          ca[s] = 2.0f * dtf * (f1i - f0i) - 8.0f * (y1i + y0i) + 16.0f * ymi;
+          cb[s] = dtf * (5.0f * f0i - 3.0f * f1i) + 18.0f * y0i + 14.0f * y1i - 32.0f * ymi;
+          cc_[s] = dtf * (f1i - 4.0f * f0i) - 11.0f * y0i - 5.0f * y1i + 16.0f * ymi;
+          cd[s] = dtf * f0i;
+        }
+        for (; j < a.T && (double)a.t[j] <= t1; ++j) {
+          const float x = (float)(((double)a.t[j] - c.t0) / (t1 - c.t0));
+          const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+          float out[NO];
+#pragma unroll
+          for (int s = 0; s < NO; ++s) out[s] = (((y[s] + x * cd[s]) + x2 * cc_[s]) + x3 * cb[s]) + x4 * ca[s];
+          Own::store(a.h + (size_t)j * row + poff, q, out, lm.live);
+        }
+      }
+      if (gid == 0) {
+        a.tape_t[c.n_acc] = c.t0;
+        a.tape_dt[c.n_acc] = c.dt;
+        a.tape_j[2 * c.n_acc] = c.j_next;
+        a.tape_j[2 * c.n_acc + 1] = j;
+      }
+      Own::store(a.tape_y + dp_tape_row(a, c.n_acc + 1) * row + poff, q, Yo, lm.live);
+      c.j_next = j;
+      c.n_acc += 1;
+      c.t0 = t1;
+#pragma unroll
+      for (int s = 0; s < NO; ++s) {
+        y[s] = Yo[s];
+        f0[s] = k[6][s];  // FSAL
+      }
+    } else {
+      c.n_rej += 1;
+    }
+    c.dt = c.dt * dp_step_factor(ratio);
+    c.attempt = seq + 1;
+    stopped = stop_now();
+  }
+  // what a continuation launch (or the launch-per-attempt path) resumes from: f0 of the current state; the state itself is
+  // tape_y[n_acc] already
+  Own::store(a.kbuf + poff, q, f0, lm.live);
+  if (gid == 0) a.ctrl[0] = c;
+}
+
+template <int D, bool ABLATE>
+__global__ __launch_bounds__(64) void dp_persist_kernel(DpArgs a) {
+  const bool hill2 = ABLATE || a.hill2 != 0;
+  if (hill2 && a.K == 1) dp_persist_body_own<D, ABLATE, true, true>(a);
+  else if (hill2) dp_persist_body_own<D, ABLATE, true, false>(a);
+  else dp_persist_body_own<D, ABLATE, false, false>(a);
 }
 
 // PHASE 2 (the attempt) runs as workgroups of up to 4 waves: a launch's fixed cost grows with the number of workgroups the
@@ -1344,7 +1543,7 @@ __global__ __launch_bounds__(64) void dp_initbwd_kernel(DpArgs a) {
 struct DpLaunch {
   int lpp;
   bool ablate, need_th;
-  int phase;  // 0 init1, 1 init2, 2 attempt, 3 backward sweep, 4 / 5 initial-step backward pass 1 / 2
+  int phase;  // 0 init1, 1 init2, 2 attempt, 3 backward sweep, 4 / 5 initial-step backward pass 1 / 2, 6 persistent attempt loop
   int waves_per_block = 1;  // attempt launches only (1..4)
 };
 
@@ -1362,6 +1561,9 @@ int dp_launch(const DpLaunch& L, const DpArgs& a, hipStream_t s) {
     case 3:
       if (L.need_th) hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((dp_bwd_kernel<D, LPP, ABLATE, false>), grid, block, 0, s, a);
+      break;
+    case 6:
+      if constexpr (LPP == 4) hipLaunchKernelGGL((dp_persist_kernel<D, ABLATE>), grid, block, 0, s, a);
       break;
     case 4:
       // pass 1 only forms a scalar; its parameter accumulators are dead code in either instantiation

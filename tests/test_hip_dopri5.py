@@ -285,3 +285,27 @@ def test_dopri5_edge_shapes(N, T, lanes):
     assert (hip["h"] - ora["h"]).abs().max().item() <= 1e-5 * (1 + ora["h"].abs().max().item())
     for k in ("gy0", "gw", "gb"):
         assert _rel(hip[k], ora[k]) <= 2e-4, (k, _rel(hip[k], ora[k]))
+
+
+def test_dopri5_persistent_attempt_loop_is_an_equivalent_opt_in(monkeypatch):
+    """HODE_DP_PERSIST=1: the whole attempt loop in one launch (waves exchange the error-norm partials through memory with a
+    bounded poll).  Slower than one launch per attempt on this part and therefore opt-in, but it must integrate the same
+    problem: same tolerance-level trajectory, gradients pinned by the replay oracle along ITS tape."""
+    from hode import adaptive
+    dev = _dev()
+    N, T, D = 100, 16, 12
+    inp, f = _setup(N, T, D, seed=52)
+    cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(3))
+    base = _hip(inp, f, dev, 4, 1e-7, 1e-8, cot, detach_first_step=True)
+    monkeypatch.setenv("HODE_DP_PERSIST", "1")
+    adaptive.keep_workspace = True
+    try:
+        per = _hip(inp, f, dev, 4, 1e-7, 1e-8, cot, detach_first_step=True)
+        tape = adaptive.read_tape()
+    finally:
+        adaptive.keep_workspace = False
+    assert abs(per["stats"]["n_accepted"] - base["stats"]["n_accepted"]) <= 0.1 * base["stats"]["n_accepted"]
+    assert (per["h"] - base["h"]).abs().max().item() <= 1e-4 * (1 + base["h"].abs().max().item())
+    rep = _replay(inp, f, 1e-7, 1e-8, cot, tape, False)
+    for k in ("gy0", "gw", "gb", "gtheta"):
+        assert _rel(per[k], rep[k]) <= 1e-5, (k, _rel(per[k], rep[k]))
