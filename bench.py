@@ -404,6 +404,82 @@ def dopri5_step(dev, rank, prob, dist=None, iters=3, cpu=True, n_cpu=256, n_par=
     return out, cpu_legs
 
 
+def other_configs(dev, iters=5):
+    """Timings of the paths the headline does not touch, so that every number quoted in DESIGN.md is in the driver's line:
+    BASELINE config 5 (DDW-shaped real-data model: one VariationalInferenceReal training step) and the NeuralODE rhs
+    (`run_simulation --method=neural`: rk4 and the reference's default dopri5) at the bench shape.  GPU only; parity of
+    these paths is held by tests/test_hip_fullsize.py, test_hip_real.py, test_hip_neural.py."""
+    import torch
+    import model
+    from hode import adaptive, synth
+    from hode.neural import neural_solve
+    out = {}
+
+    def timed(fn):
+        fn()
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    # ---- config 5
+    obs, act, stat, Dr, Tr, t0r, Br = 24, 1, 11, 20, 120, 24, 8192
+    input_dim = obs + act + stat + 1
+    torch.manual_seed(0)
+    enc = model.EncoderLSTMReal(input_dim, int(input_dim * 1.2), Dr, output_all=False, reverse=False, device=dev)
+    dec = model.DecoderReal(obs, Dr, act, stat, int((obs + act + stat) * 1.2), Tr, 1, method="midpoint", ode_step_size=1.0,
+                            ode_type="hybrid", t0=t0r, device=dev)
+    vi = model.VariationalInferenceReal(enc, dec, elbo=True, t0=t0r)
+    g = torch.Generator().manual_seed(1)
+    data = {"measurements": torch.randn(Tr, Br, obs, generator=g).to(dev),
+            "actions": ((torch.rand(Tr, Br, 1, generator=g) < 0.1).float() * torch.rand(Tr, Br, 1, generator=g)).to(dev),
+            "masks": (torch.rand(Tr, Br, obs, generator=g) < 0.5).float().to(dev),
+            "statics": torch.rand(Tr, Br, stat, generator=g).to(dev)}
+
+    def real_step():
+        for p in vi.parameters():
+            p.grad = None
+        vi.loss(data).backward()
+
+    ms = timed(real_step)
+    out["config5_real_data_step"] = {"ms": ms, "trajectories_per_s": Br / ms * 1e3,
+                                     "what": "VariationalInferenceReal loss + backward, %d patients x T=%d (t0=%d), obs 24, statics 11, D=20, "
+                                             "encoder 37->44 (MFMA LSTM), RocheODEReal midpoint+perturb (MFMA rhs, weight gradients on chip), "
+                                             "fused two-layer readout + masked SSE" % (Br, Tr, t0r)}
+    del vi, enc, dec, data
+    # ---- NeuralODE rhs at the bench shape
+    inp = synth.solver_inputs(N_PER_GPU, T, D)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(D + 1, 10 * D), torch.nn.Tanh(), torch.nn.Linear(10 * D, D), torch.nn.Tanh())
+    prm = [p.detach().clone().to(dev).requires_grad_(True) for p in (net[0].weight, net[0].bias, net[2].weight, net[2].bias)]
+    y0 = inp["z0"].to(dev).requires_grad_(True)
+    chan = inp["actions"][..., 0]
+    dosage = chan.max(dim=0)[0].to(dev)
+    times = (torch.nonzero((chan != 0).t())[:, 1].reshape(N_PER_GPU, -1) * synth.STEP).float().to(dev)
+    tt = inp["t"].to(dev)
+    cot = torch.randn(T, N_PER_GPU, D, device=dev)
+
+    def run(solve):
+        def f():
+            y0.grad = None
+            for q in prm:
+                q.grad = None
+            (solve() * cot).sum().backward()
+        return f
+
+    ms_rk4 = timed(run(lambda: neural_solve(y0, *prm, tt, dosage, times, method="rk4")))
+    ms_dp = timed(run(lambda: adaptive.neural_dopri5(y0, *prm, tt, dosage, times, rtol=1e-7, atol=1e-8)))
+    st = dict(adaptive.last_stats)
+    out["neural_rhs"] = {"rk4_solve_adjoint_ms": ms_rk4, "dopri5_solve_adjoint_ms": ms_dp,
+                         "dopri5_attempts": st["n_accepted"] + st["n_rejected"],
+                         "what": "NeuralODE rhs (13 -> 120 -> 12 on the matrix cores), %d patients x T=%d, forward + adjoint incl. "
+                                 "on-chip weight gradients" % (N_PER_GPU, T)}
+    return out
+
+
 def kernel_times(plan, iters=20):
     """Average duration of the forward kernel and of the adjoint kernel ALONE (no memset, no partial fold -- the quantity
     rocprofv3's kernel stats report), plus the whole backward call, from HIP events on the launch stream."""
@@ -557,6 +633,7 @@ def main():
     dp, dp_cpu = dopri5_step(dev, rank, prob, dist, cpu=cpu) if extras else (None, None)  # every rank takes part (collective)
     if rank == 0:
         fs, fs_cpu = full_training_step(dev, cpu=cpu) if extras else (None, None)
+        others = other_configs(dev) if extras and world == 1 else None
         fwd_s, bwd_s, bwd_call_s = kt
         ms = elapsed / args.steps * 1e3
         total = N_PER_GPU * world
@@ -611,6 +688,8 @@ def main():
             dp_cpu()
             out["full_training_step"] = fs
             out["dopri5_step"] = dp
+            if others is not None:
+                out["other_configs"] = others
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
