@@ -309,3 +309,39 @@ def test_dopri5_persistent_attempt_loop_is_an_equivalent_opt_in(monkeypatch):
     rep = _replay(inp, f, 1e-7, 1e-8, cot, tape, False)
     for k in ("gy0", "gw", "gb", "gtheta"):
         assert _rel(per[k], rep[k]) <= 1e-5, (k, _rel(per[k], rep[k]))
+
+
+def test_dopri5_without_a_tape_is_the_same_forward():
+    """HODE_FLAG_NO_TAPE (no input needs a gradient: evaluate() under no_grad): two state rows addressed by step parity
+    instead of (max_steps + 1) rows -- same attempts, bit-identical trajectory, both rhs families; and the workspace does
+    not grow with the step bound."""
+    from hode import adaptive, synth
+    from hode.solver import pack_theta
+    dev = _dev()
+    N, T, D = 150, 24, 12
+    inp, f = _setup(N, T, D, seed=61)
+    with_tape = _hip(inp, f, dev, 0, 1e-7, 1e-8)
+    scal = [getattr(f, n).detach().to(dev) for n in THETA_NAMES]
+    dosage, times = dose_schedule(inp["actions"], f.step_size)
+    args = (inp["z0"].to(dev), pack_theta(scal, dev), f.ml_net[0].weight.detach().to(dev), f.ml_net[0].bias.detach().to(dev),
+            inp["t"].to(dev), dosage.to(dev), times.to(dev))
+    adaptive.keep_workspace = True
+    try:
+        with torch.no_grad():
+            h = adaptive.roche_dopri5(*args, rtol=1e-7, atol=1e-8)
+        ws_bytes = adaptive._last_ws[0].numel()
+    finally:
+        adaptive.keep_workspace = False
+    assert dict(adaptive.last_stats) == with_tape["stats"] and torch.equal(h.cpu(), with_tape["h"])
+    assert ws_bytes < 40 * N * D * 4 + (1 << 20) * 24 + (1 << 20)  # state rows + 24 B of time records per allowed step
+    # neural rhs
+    from oracle.rhs import NeuralRHS
+    torch.manual_seed(3)
+    g = NeuralRHS(D, synth.STEP)
+    prm = [p.detach().to(dev) for p in (g.ml_net[0].weight, g.ml_net[0].bias, g.ml_net[2].weight, g.ml_net[2].bias)]
+    y0 = (inp["z0"] * 30).to(dev)
+    h_tape = adaptive.neural_dopri5(y0.clone().requires_grad_(True), *prm, args[4], args[5], args[6], rtol=1e-6, atol=1e-8)
+    st = dict(adaptive.last_stats)
+    with torch.no_grad():
+        h_ring = adaptive.neural_dopri5(y0, *prm, args[4], args[5], args[6], rtol=1e-6, atol=1e-8)
+    assert dict(adaptive.last_stats) == st and torch.equal(h_ring, h_tape.detach())
