@@ -22,6 +22,7 @@ DP_DIMS = (4, 6, 8, 12)
 EXTRA_FLAGS = {"hode_rk_split": os.environ.get("HODE_SPLIT_FLAGS", "-fno-slp-vectorize").split()}
 DP_FLAGS = os.environ.get("HODE_DP_FLAGS", "").split()  # experiments on the dopri5 units only; product builds: empty
 EXTRA_FLAGS["hode_dopri5"] = DP_FLAGS
+EXTRA_FLAGS["hode_lstm"] = os.environ.get("HODE_LSTM_FLAGS", "").split()  # diagnostics (-DHODE_LSTM_STAMPS); product builds: empty
 
 
 def units():

@@ -317,6 +317,7 @@ struct LstmBwdArgs {
                                        // (AD) | hidden state entering the step (H) | 1.0 | zero padding to W
   const float* __restrict__ a;         // [T][B][AD] or nullptr
   int T, B, H, Hp, LD, reverse, AD, OBS, W;
+  unsigned long long* dbg;  // HODE_LSTM_STAMPS builds only: [T][8] s_memtime stamps of wave 0 of block 0
 };
 
 __global__ void lstm_pack_hh_kernel(const float* __restrict__ w_hh, float* __restrict__ whp, int H, int TPW) {
@@ -401,8 +402,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     load_ops(oa, wa, whb, tc0, tpv0, 0);
   }
 
+#ifdef HODE_LSTM_STAMPS
+#define HODE_LSTAMP(i) if (p.dbg && blockIdx.x == 0 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); p.dbg[(size_t)s * 8 + (i)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define HODE_LSTAMP(i)
+#endif
   for (int s = p.T - 1; s >= 0; --s) {
     const int t = p.reverse ? p.T - 1 - s : s;
+    HODE_LSTAMP(0)
     const float *tc, *tpv, *tc_n, *tpv_n;
     step_ptrs(s, tc, tpv);
     step_ptrs(s > 0 ? s - 1 : 0, tc_n, tpv_n);  // next step's first tile (s == 0: a harmless repeat)
@@ -417,6 +424,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int mt = 0; mt < TPW; ++mt)
 #pragma unroll
       for (int c = 0; c < NT; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The columns of the GEMM operand row that do not depend on the recurrence -- the action columns (a copy of an input),
+    // the constant 1 of the bias column, the zero padding -- are written HERE, ahead of the tile loop: inside the store
+    // phase each patient's action copy was a dependent global load -> store (12 serial HBM round trips per wave and step,
+    // 5.8 us of a 36.6 us step; tools/lstm_stamp_probe.py).
+    {
+      const int W = p.W, I = p.OBS + p.AD;
+      float* hdst = p.h_prev + ((size_t)t * p.B + b0) * W;
+      const float* asrc = p.a ? p.a + ((size_t)t * p.B + b0) * p.AD : nullptr;
+      const int nA = nvalid * p.AD, nP = nvalid * (W - I - H);
+      for (int e = tid; e < nA; e += 256) {
+        const int b = e / p.AD, u = e - b * p.AD;
+        hdst[(size_t)b * W + p.OBS + u] = asrc[e];
+      }
+      for (int e = tid; e < nP; e += 256) {
+        const int b = e / (W - I - H), u = e - b * (W - I - H);
+        hdst[(size_t)b * W + I + H + u] = u == 0 ? 1.0f : 0.0f;
+      }
+    }
 
     auto tile = [&](int tt, const TapeOps& o, const f32x4 (&wf)[TPW], TapeOps& o_nx, f32x4 (&wf_nx)[TPW]) {
       if (tt + 1 < TPW) load_ops(o_nx, wf_nx, wh, tc, tpv, tt + 1);
@@ -437,7 +462,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dgr[c][3] = dh * tcn * go * (1.0f - go);
         carry_c[tt][c] = dc * gf;
         const int b = 16 * c + pc;
-        if (u < Hp) {
+        if (u < Hp) {  // always true (u < 16 TPW); kept: without the branch the scheduler merges the ten tiles into one block and
+                       // the tile loop takes 47 us instead of 26 (measured, tools/lstm_stamp_probe.py)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dgt[(size_t)b * LDG + r * Hp + u] = dgr[c][r];
           hT[(size_t)b * LDH + u] = h_prev;
@@ -461,7 +487,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int mt = 0; mt < TPW; ++mt) wa[mt] = wb[mt];
     }
+    HODE_LSTAMP(1)
     __syncthreads();
+    HODE_LSTAMP(2)
     // coalesced row-major stores of this step's dG and h_prev tiles.  Wave w stores patients w, w+4, ...; the loops run
     // over (patient, gate, unit) explicitly -- a flat index would need two integer divisions per element, which made
     // this transposition the longest phase of the step (120 iterations x ~70 instructions per thread).
@@ -470,27 +498,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int W = p.W, I = p.OBS + p.AD;
       float* hdst = p.h_prev + ((size_t)t * p.B + b0) * W;
       const float* asrc = p.a ? p.a + ((size_t)t * p.B + b0) * p.AD : nullptr;
-      for (int b = w; b < nvalid; b += 4) {
+      // The LDS reads of a patient's rows are all issued before the first store (and two patients are in flight): with one
+      // ds_read -> wait -> global_store chain per 16 bytes this phase was LDS-LATENCY bound -- 84 dependent round trips per
+      // wave and step, 8.6 us of a 36.6 us step (tools/lstm_stamp_probe.py) -- not bandwidth bound.
+      const bool vec = (H & 3) == 0;
+      const bool lane_g = 4 * l < H;           // H <= 160: one 16-byte chunk per lane and gate row covers a row
+      for (int b = w; b < nvalid; b += 8) {
+        const int b2 = b + 4;
+        const bool two = b2 < nvalid;
         const float* drow = dgt + (size_t)b * LDG;
-        float* grow = gdst + (size_t)b * 4 * H;
-        if ((H & 3) == 0) {  // 16-byte rows: one ds_read_b128 + one global_store_dwordx4 per 4 gate values
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            for (int u = 4 * l; u < H; u += 256)
-              *reinterpret_cast<f32x4*>(grow + r * H + u) = *reinterpret_cast<const f32x4*>(drow + r * Hp + u);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            for (int u = l; u < H; u += 64) grow[r * H + u] = drow[r * Hp + u];
-        }
+        const float* drow2 = dgt + (size_t)(two ? b2 : b) * LDG;
         const float* hrow = hT + (size_t)b * LDH;
-        float* hd = hdst + (size_t)b * W;
-        for (int u = l; u < p.AD; u += 64) hd[p.OBS + u] = asrc[(size_t)b * p.AD + u];
-        for (int u = l; u < H; u += 64) hd[I + u] = hrow[u];
-        for (int u = I + H + l; u < W; u += 64) hd[u] = (u == I + H) ? 1.0f : 0.0f;
+        const float* hrow2 = hT + (size_t)(two ? b2 : b) * LDH;
+        f32x4 v[4], v2[4];
+        float hv[3], hv2[3];
+        if (vec) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = lane_g ? *reinterpret_cast<const f32x4*>(drow + r * Hp + 4 * l) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v2[r] = lane_g ? *reinterpret_cast<const f32x4*>(drow2 + r * Hp + 4 * l) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          hv[k] = (l + 64 * k < H) ? hrow[l + 64 * k] : 0.f;
+          hv2[k] = (l + 64 * k < H) ? hrow2[l + 64 * k] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the stores
+        auto put = [&](int bb, const float* dr, const f32x4 (&vv)[4], const float (&hh)[3]) {
+          float* grow = gdst + (size_t)bb * 4 * H;
+          if (vec) {
+            if (lane_g) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(grow + r * H + 4 * l) = vv[r];
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              for (int u = l; u < H; u += 64) grow[r * H + u] = dr[r * Hp + u];
+          }
+          float* hd = hdst + (size_t)bb * W;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (l + 64 * k < H) hd[I + l + 64 * k] = hh[k];
+        };
+        put(b, drow, v, hv);
+        if (two) put(b2, drow2, v2, hv2);
       }
     }
+    HODE_LSTAMP(3)
     __syncthreads();
+    HODE_LSTAMP(4)
     // exchange the K-split partial products: slab[w][u'][patient]
 #pragma unroll
     for (int mt = 0; mt < TPW; ++mt)
@@ -499,7 +557,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
           slab[((size_t)w * Hp + 16 * mt + 4 * g + rr) * LD + 16 * c + pc] = acc[mt][c][rr];
+    HODE_LSTAMP(5)
     __syncthreads();
+    HODE_LSTAMP(6)
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
       const int u = (w * TPW + tt) * 4 + g;
@@ -509,8 +569,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         carry_h[tt][c] = ((sp[0] + sp[(size_t)Hp * LD]) + sp[(size_t)2 * Hp * LD]) + sp[(size_t)3 * Hp * LD];
       }
     }
+    HODE_LSTAMP(7)
     __syncthreads();
   }
+#undef HODE_LSTAMP
 }
 
 }  // namespace hode
@@ -713,6 +775,9 @@ extern "C" int hode_lstm_bwd(const hode_lstm_desc* d, void* stream) {
   a.T = d->seq_len; a.B = d->batch; a.H = d->hidden_dim; a.Hp = G.Hp; a.LD = G.LD; a.reverse = d->reverse;
   a.a = d->a; a.AD = d->input_dim - d->obs_dim;
   a.OBS = d->obs_dim; a.W = (d->input_dim + d->hidden_dim + 1 + 3) / 4 * 4;
+#ifdef HODE_LSTM_STAMPS
+  if (const char* env = getenv("HODE_LSTM_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(env, nullptr, 0);
+#endif
   switch (G.NT) {
     case 1: return launch_bwd_tpw<1>(G, a, s);
     case 2: return launch_bwd_tpw<2>(G, a, s);
