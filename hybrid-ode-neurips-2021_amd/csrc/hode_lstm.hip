@@ -32,12 +32,12 @@ struct LstmArgs {
   const float* __restrict__ x;
   const float* __restrict__ a;
   const float* __restrict__ mask;
-  const float* __restrict__ wp;     // packed Wcat fragments [4][KQ4][TPW][64][4]
-  const float* __restrict__ bp;     // packed bias [4][TPW][64][4]
+  const float* __restrict__ wp;     // packed Wcat fragments [4][KQ4][TPW][64][4]; operand row I + Hp is the bias
   float* __restrict__ h_out;
   float* __restrict__ c_out;
-  float* __restrict__ tape;         // [T][nblk][4][TPW][NT][5][64] or nullptr
+  float* __restrict__ tape;         // [T][nblk][Hp/16 (unit tile = wave * TPW + tile of the wave)][NT][5][64] or nullptr
   int T, B, OBS, AD, I, H, Hp, Kq, KQ4, LD, reverse;
+  unsigned long long* dbg;  // HODE_LSTM_STAMPS builds only: [T][8] s_memtime stamps of wave 0 of block 0
 };
 
 HODE_DEV float sigmoid_gate(float x) {
@@ -45,134 +45,136 @@ HODE_DEV float sigmoid_gate(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
-// ---- weight / bias packing (once per forward: the optimiser changes the weights every step)
+// ---- weight / bias packing (once per forward: the optimiser changes the weights every step).  The bias b_ih + b_hh is
+// operand row k = I + Hp of Wcat: the activation buffers hold a row of ones there, so the accumulators start from zero
+// and no register holds a bias.
 __global__ void lstm_pack_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
                                  const float* __restrict__ b_ih, const float* __restrict__ b_hh, float* __restrict__ wp,
-                                 float* __restrict__ bp, int I, int H, int TPW, int KQ4) {
-  const long long n_w = 4LL * KQ4 * TPW * 64 * 4;
-  const long long n_b = 4LL * TPW * 64 * 4;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n_w + n_b;
-       idx += (long long)gridDim.x * blockDim.x) {
-    if (idx < n_w) {
-      const int kk = idx & 3;
-      const int l = (idx >> 2) & 63;
-      long long r = idx >> 8;
-      const int tau = (int)(r % TPW); r /= TPW;
-      const int kq4 = (int)(r % KQ4);
-      const int w = (int)(r / KQ4);
-      const int i = l & 15;
-      const int u = (w * TPW + tau) * 4 + (i >> 2);
-      const int gate = i & 3;
-      const int k = 4 * (4 * kq4 + kk) + (l >> 4);
-      float v = 0.f;
-      if (u < H) {
-        const int row = gate * H + u;
-        if (k < I) v = w_ih[(size_t)row * I + k];
-        else if (k - I < H) v = w_hh[(size_t)row * H + (k - I)];
-      }
-      wp[idx] = v;
-    } else {
-      const long long j = idx - n_w;
-      const int gate = j & 3;
-      const int l = (j >> 2) & 63;
-      long long r = j >> 8;
-      const int tau = (int)(r % TPW);
-      const int w = (int)(r / TPW);
-      const int u = (w * TPW + tau) * 4 + (l >> 4);
-      bp[j] = u < H ? b_ih[gate * H + u] + b_hh[gate * H + u] : 0.f;
+                                 int I, int H, int TPW, int NW, int KQ4) {
+  const long long n_w = (long long)NW * KQ4 * TPW * 64 * 4;   // NW waves x TPW tiles x (4 units x 4 gates)
+  const int Hp = 4 * TPW * NW;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n_w; idx += (long long)gridDim.x * blockDim.x) {
+    const int kk = idx & 3;
+    const int l = (idx >> 2) & 63;
+    long long r = idx >> 8;
+    const int tau = (int)(r % TPW); r /= TPW;
+    const int kq4 = (int)(r % KQ4);
+    const int w = (int)(r / KQ4);
+    const int i = l & 15;
+    const int u = (w * TPW + tau) * 4 + (i >> 2);
+    const int gate = i & 3;
+    const int k = 4 * (4 * kq4 + kk) + (l >> 4);
+    float v = 0.f;
+    if (u < H) {
+      const int row = gate * H + u;
+      if (k < I) v = w_ih[(size_t)row * I + k];
+      else if (k - I < H) v = w_hh[(size_t)row * H + (k - I)];
+      else if (k == I + Hp) v = b_ih[row] + b_hh[row];
     }
+    wp[idx] = v;
   }
 }
 
 // ---- forward
-template <int NT, int TPW>
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
+// NW waves of TPW 16-row tiles each (NW * TPW * 16 = padded H).  Hp = 160 runs as 8 waves x 5 tiles: two waves per
+// SIMD, every register in the 256-entry VGPR file -- with 4 x 10 the 120 accumulators went to the AGPR half and came
+// back through v_accvgpr moves every step, the compiler spilled, and nothing covered a non-MFMA instruction.
+// VEC4: obs_dim % 4 == 0 (x tile fetched in 16-byte groups).  A compile-time switch: as a run-time branch the flat
+// path's per-element divisions are hoisted out of the step loop and pinned ~60 registers in every shipped shape.
+template <int NT, int TPW, int NW, bool VEC4>
+__global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
+  constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BT = 16 * NT;
   const int tid = threadIdx.x;
-  const int w = tid >> 6, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;  // w in an SGPR: per-wave bases stay scalar
   const int g = l >> 4, pc = l & 15;
   const int b0 = blockIdx.x * BT;
   const int nvalid = min(BT, p.B - b0);
-  const int LD = p.LD;
+  // compile-time leading dimension (== p.LD, lstm_geom): LDS offsets of the unrolled tile loops become instruction
+  // immediates instead of one hoisted address register per (tile, patient column, buffer)
+  constexpr int LD = BT + ((BT % 32 == 0) ? 16 : 0);
   const int Krows = 4 * p.Kq;                  // rows of one activation buffer (zero padded past I + Hp)
   float* act0 = lds;
   float* act1 = lds + (size_t)Krows * LD;
 
-  // zero both activation buffers (h_{-1} = 0, padding rows/columns stay 0 forever)
-  for (int e = tid; e < 2 * Krows * LD; e += 256) lds[e] = 0.f;
+  // zero both activation buffers (h_{-1} = 0, padding rows/columns stay 0 forever); row I + Hp is the bias row: ones
+  const int one_row = p.I + p.Hp;
+  for (int e = tid; e < 2 * Krows * LD; e += NTHR) {
+    const int r = (e / LD) % Krows;
+    lds[e] = r == one_row ? 1.f : 0.f;
+  }
 
-  // bias-initialised accumulators are rebuilt every step from these registers
-  f32x4 bias[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) bias[t] = *reinterpret_cast<const f32x4*>(p.bp + ((size_t)(w * TPW + t) * 64 + l) * 4);
   float cst[TPW][NT];
-  float hlast[TPW][NT];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
-    for (int c = 0; c < NT; ++c) cst[t][c] = hlast[t][c] = 0.f;
+    for (int c = 0; c < NT; ++c) cst[t][c] = 0.f;
 
   // x tile staging: the tile of one step is BT*OBS contiguous floats (patients are contiguous in [T][B][OBS]).
   // OBS % 4 == 0 (every shipped shape): a thread owns 16-byte groups (patient b = idx % BT, group idx / BT) -- consecutive
   // lanes are consecutive PATIENTS, so the k-major LDS writes are conflict free (the flat element order wrote a wave's
   // 64 values into 2 banks) and no run-time division is needed; the 16-byte loads walk every cache line four times
   // within the step, which L1 / L2 absorb.  Otherwise: flat element order, one division per element.
-  constexpr int XPT = 20;  // staged floats per thread (covers BT*OBS <= 5120)
+  // The loads are UNCONDITIONAL (slots past the tile read element 0 and are zeroed when staged) and x * mask is formed
+  // when the tile is staged, not when it is fetched: a guarded load followed by the product is one basic block with a
+  // vmcnt(0) per 16-byte group -- five serialised HBM round trips (6 us) in front of every step's first MFMA.
+  constexpr int XPT = NW == 8 ? 12 : 20;  // staged floats per thread (XPT * NTHR covers BT*OBS <= 5120; multiple of 4)
   const int n_x = nvalid * p.OBS;
-  const bool vec4 = (p.OBS & 3) == 0;
+  constexpr bool vec4 = VEC4;
   const int Q4 = p.OBS >> 2;
-  float xs[XPT];
+  const bool has_mask = p.mask != nullptr;
+  float xs[XPT], ms[XPT];
   auto fetch_x = [&](int t) {
     const size_t base = ((size_t)t * p.B + b0) * p.OBS;
-    if (vec4) {
+    const float* xb = p.x + base;
+    const float* mb = has_mask ? p.mask + base : xb;   // no mask: the second load repeats the first (L1 hit), never used
+    if constexpr (vec4) {
 #pragma unroll
       for (int j = 0; j < XPT / 4; ++j) {
-        const int idx = tid + 256 * j;
+        const int idx = tid + NTHR * j;
         const int b = idx % BT, i4 = idx / BT;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (i4 < Q4 && b < nvalid) {
-          v = *reinterpret_cast<const f32x4*>(p.x + base + (size_t)b * p.OBS + 4 * i4);
-          if (p.mask) v *= *reinterpret_cast<const f32x4*>(p.mask + base + (size_t)b * p.OBS + 4 * i4);
-        }
+        const int off = (i4 < Q4 && b < nvalid) ? b * p.OBS + 4 * i4 : 0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + off);
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mb + off);
         xs[4 * j] = v[0]; xs[4 * j + 1] = v[1]; xs[4 * j + 2] = v[2]; xs[4 * j + 3] = v[3];
+        ms[4 * j] = m[0]; ms[4 * j + 1] = m[1]; ms[4 * j + 2] = m[2]; ms[4 * j + 3] = m[3];
       }
     } else {
 #pragma unroll
       for (int j = 0; j < XPT; ++j) {
-        const int e = tid + 256 * j;
-        float v = 0.f;
-        if (e < n_x) {
-          v = p.x[base + e];
-          if (p.mask) v *= p.mask[base + e];
-        }
-        xs[j] = v;
+        const int e = tid + NTHR * j;
+        const int off = e < n_x ? e : 0;
+        xs[j] = xb[off];
+        ms[j] = mb[off];
       }
     }
   };
   auto stage_x = [&](float* dst, int t) {
-    if (vec4) {
+    if constexpr (vec4) {
 #pragma unroll
       for (int j = 0; j < XPT / 4; ++j) {
-        const int idx = tid + 256 * j;
+        const int idx = tid + NTHR * j;
         const int b = idx % BT, i4 = idx / BT;
         if (i4 < Q4) {
+          const bool live = b < nvalid;  // zeros for patients past the batch
 #pragma unroll
-          for (int c = 0; c < 4; ++c) dst[(4 * i4 + c) * LD + b] = xs[4 * j + c];  // zeros for patients past the batch
+          for (int c = 0; c < 4; ++c)
+            dst[(4 * i4 + c) * LD + b] = live ? (has_mask ? xs[4 * j + c] * ms[4 * j + c] : xs[4 * j + c]) : 0.f;
         }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < XPT; ++j) {
-        const int e = tid + 256 * j;
+        const int e = tid + NTHR * j;
         if (e < n_x) {
           const int b = e / p.OBS, i = e - b * p.OBS;
-          dst[i * LD + b] = xs[j];
+          dst[i * LD + b] = has_mask ? xs[j] * ms[j] : xs[j];
         }
       }
     }
     // action columns (never masked): AD * nvalid values
-    for (int e = tid; e < nvalid * p.AD; e += 256) {
+    for (int e = tid; e < nvalid * p.AD; e += NTHR) {
       const int b = e / p.AD, i = e - b * p.AD;
       dst[(p.OBS + i) * LD + b] = p.a[((size_t)t * p.B + b0 + b) * p.AD + i];
     }
@@ -184,15 +186,24 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
   stage_x(act0, t_first);
   __syncthreads();
 
-  const f32x4* wbase = reinterpret_cast<const f32x4*>(p.wp) + (size_t)w * p.KQ4 * TPW * 64 + l;
+  const f32x4* wbase = reinterpret_cast<const f32x4*>(p.wp) + (size_t)w * p.KQ4 * TPW * 64;  // wave-uniform; lane index added per load
   // weight fragment registers live across steps: the first group of step s+1 is requested as soon as step s's MFMA loop
   // ends, so its L2 round trip runs under the cell update, the x staging and the barrier
   f32x4 wa[TPW], wb[TPW];
 #pragma unroll
-  for (int tt = 0; tt < TPW; ++tt) wa[tt] = wbase[(size_t)tt * 64];
+  for (int tt = 0; tt < TPW; ++tt) wa[tt] = wbase[tt * 64 + l];
 
+#ifdef HODE_LSTM_STAMPS
+#define HODE_FSTAMP(i) if (p.dbg && blockIdx.x == 0 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); p.dbg[(size_t)s * 8 + (i)] = __builtin_amdgcn_s_memtime(); }
+// no-wait stamps inside the MFMA section: slot [T + s][16]
+#define HODE_GSTAMP(i) if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[(size_t)(p.T + s) * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define HODE_FSTAMP(i)
+#define HODE_GSTAMP(i)
+#endif
   for (int s = 0; s < p.T; ++s) {
     const int t = p.reverse ? p.T - 1 - s : s;
+    HODE_FSTAMP(0)
     float* cur = (s & 1) ? act1 : act0;
     float* nxt = (s & 1) ? act0 : act1;
     const bool more = s + 1 < p.T;
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-      for (int c = 0; c < NT; ++c) acc[tt][c] = bias[tt];
+      for (int c = 0; c < NT; ++c) acc[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};  // the bias arrives through the ones row
 
     // software-pipelined weight fragments: group q+1 is loaded while group q feeds the matrix pipe.  The loop over
     // full groups (4 k-quads each) is branch-free; the partial last group is peeled -- with a conditional per k-quad
@@ -211,7 +222,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
     // issued (one L2 round trip per group, 16 per step).
     // B fragments (one LDS row per patient column) are read one k-quad ahead: read-then-use in front of every 30-MFMA
     // block would expose the LDS latency 61 times per step
-    float bf[NT];
+    auto load_group0 = [&](f32x4 (&wf)[TPW]) {
+#pragma unroll
+      for (int tt = 0; tt < TPW; ++tt) wf[tt] = wbase[tt * 64 + l];
+    };
+    // Nothing in the loop copies a register: weight fragments alternate between wa / wb over PAIRS of groups and the B
+    // fragments between bf / bn over pairs of k-quads -- with one wave per SIMD nothing else covers an instruction
+    // that is not an MFMA, and the 40 + 12 moves, the 10 loads and their addresses cost 500 cycles per group (13 %)
+    // when they sat between the MFMA blocks.  The prefetch loads are pinned one in front of every 3 MFMAs of the
+    // group's first k-quad, where they issue while the matrix pipe is busy.
+    float bf[NT], bn[NT];
     const int last_quad = p.Kq - 1;
     auto read_b = [&](float (&dst)[NT], int quad) {
       const float* rowp = cur + (size_t)(4 * min(quad, last_quad) + g) * LD + pc;
@@ -219,13 +239,38 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
       for (int c = 0; c < NT; ++c) dst[c] = rowp[16 * c];
     };
     read_b(bf, 0);
-    auto quads = [&](const f32x4 (&wf)[TPW], int q, int kk_begin, int kk_end) {
+    // one full group: 4 k-quads out of wf, B fragments bf -> bn -> bf -> bn -> bf; wn <- group qn during k-quad 0
+    auto group4 = [&](const f32x4 (&wf)[TPW], f32x4 (&wn)[TPW], int q, int qn) {
+      const f32x4* wq = wbase + (size_t)qn * TPW * 64;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        if (kk >= kk_begin && kk < kk_end) {
-          float bn[NT];
+        float (&bc)[NT] = (kk & 1) ? bn : bf;
+        float (&bx)[NT] = (kk & 1) ? bf : bn;
+        read_b(bx, 4 * q + kk + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the read HERE: the scheduler would sink it next to its use
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+          if (kk == 0) wn[tt] = wq[tt * 64 + l];
+#pragma unroll
+          for (int c = 0; c < NT; ++c)
+            acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][kk], bc[c], acc[tt][c], 0, 0, 0);
+        }
+        if (kk == 0) {
+#pragma unroll
+          for (int tt = 0; tt < TPW; ++tt) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one weight load ...
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // ... per NT MFMAs
+          }
+        }
+      }
+    };
+    // the partial last group (its fragments are zero padded): once per step, moves do not matter here
+    auto group_tail = [&](const f32x4 (&wf)[TPW], int q, int n) {
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        if (kk < n) {
           read_b(bn, 4 * q + kk + 1);
-          __builtin_amdgcn_sched_barrier(0);  // keep the read HERE: the scheduler would sink it next to its use
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
@@ -236,24 +281,36 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
         }
       }
     };
-    auto load_group = [&](f32x4 (&wf)[TPW], int q) {
-#pragma unroll
-      for (int tt = 0; tt < TPW; ++tt) wf[tt] = wbase[((size_t)q * TPW + tt) * 64];
-    };
     const int n_full = p.Kq >> 2;        // groups with all 4 k-quads
-    const int tail = p.Kq & 3;           // k-quads of the last, partial group (its fragments are zero padded)
+    const int tail = p.Kq & 3;           // k-quads of the last, partial group
     const int n_groups = n_full + (tail ? 1 : 0);
-    for (int q = 0; q < n_full; ++q) {
-      load_group(wb, min(q + 1, n_groups - 1));  // clamped: the last prefetch may be a repeat, never out of bounds
-      quads(wa, q, 0, 4);
-#pragma unroll
-      for (int tt = 0; tt < TPW; ++tt) wa[tt] = wb[tt];
+    int q = 0;
+    HODE_GSTAMP(10)
+    for (; q + 2 <= n_full; q += 2) {
+      HODE_GSTAMP(q >> 1)
+      group4(wa, wb, q, q + 1);
+      group4(wb, wa, q + 1, min(q + 2, n_groups - 1));  // clamped: the last prefetch may be a repeat, never out of bounds
     }
-    if (tail) quads(wa, n_full, 0, tail);
-    load_group(wa, 0);  // next step's first group (weights do not change within the launch)
+    HODE_GSTAMP(8)
+    // wa holds group q; the step's last prefetch goes to group 0 of the next step (weights do not change in the launch)
+    if (n_full & 1) {
+      group4(wa, wb, q, tail ? n_full : 0);
+      if (tail) {
+        group_tail(wb, n_full, tail);
+        load_group0(wa);
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) wa[tt] = wb[tt];
+      }
+    } else {
+      if (tail) group_tail(wa, n_full, tail);
+      load_group0(wa);
+    }
+    HODE_GSTAMP(9)
+    HODE_FSTAMP(1)
 
     // cell update: lane (g, pc) holds gates i,f,g,o of unit u = (w*TPW + tt)*4 + g for patient 16c + pc
-    float* tp = p.tape ? p.tape + (((size_t)t * gridDim.x + blockIdx.x) * 4 + w) * TPW * NT * 5 * 64 + l : nullptr;
+    float* tp = p.tape ? p.tape + (((size_t)t * gridDim.x + blockIdx.x) * NW + w) * TPW * NT * 5 * 64 : nullptr;  // wave-uniform
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
       const int u = (w * TPW + tt) * 4 + g;
@@ -266,19 +323,27 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
         const float cn = __builtin_fmaf(gf, cst[tt][c], gi * gg);
         const float hn = go * tanh_f32(cn);
         cst[tt][c] = cn;
-        hlast[tt][c] = hn;
         nxt[(size_t)(p.I + u) * LD + 16 * c + pc] = hn;
         if (tp) {
-          float* q5 = tp + (size_t)(tt * NT + c) * 5 * 64;
-          q5[0] = gi; q5[64] = gf; q5[128] = gg; q5[192] = go; q5[256] = cn;
+          float* q5 = tp + (tt * NT + c) * 5 * 64;
+          q5[l] = gi; q5[64 + l] = gf; q5[128 + l] = gg; q5[192 + l] = go; q5[256 + l] = cn;
         }
       }
+      // one tile's NT patient columns at a time: interleaving all TPW * NT exp / rcp chains costs more registers than
+      // the file has next to the accumulators (the other wave of the SIMD covers the latency instead)
+      __builtin_amdgcn_sched_barrier(0);
     }
+    HODE_FSTAMP(2)
     if (more) stage_x(nxt, t_next);
+    HODE_FSTAMP(3)
     __syncthreads();
+    HODE_FSTAMP(4)
   }
+#undef HODE_FSTAMP
+#undef HODE_GSTAMP
 
-  // final state
+  // final state: h_T is what the last step left in its output buffer (each lane reads back its own values)
+  const float* fin = (p.T & 1) ? act1 : act0;
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     const int u = (w * TPW + tt) * 4 + g;
@@ -286,7 +351,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs p) {
     for (int c = 0; c < NT; ++c) {
       const int b = 16 * c + pc;
       if (u < p.H && b < nvalid) {
-        p.h_out[(size_t)(b0 + b) * p.H + u] = hlast[tt][c];
+        p.h_out[(size_t)(b0 + b) * p.H + u] = fin[(size_t)(p.I + u) * LD + b];
         p.c_out[(size_t)(b0 + b) * p.H + u] = cst[tt][c];
       }
     }
@@ -584,7 +649,7 @@ using hode::LstmArgs;
 
 struct LstmGeom {
   int Hp, TPW, NT, BT, nblk, Kq, KQ4, LD;
-  size_t wp_floats, bp_floats, tape_floats, whp_floats, lds_bytes, lds_bwd_bytes;
+  size_t wp_floats, tape_floats, whp_floats, lds_bytes, lds_bwd_bytes;
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -615,11 +680,10 @@ int lstm_geom(const hode_lstm_desc* d, LstmGeom* G, bool bwd_compatible) {
   }
   G->BT = 16 * G->NT;
   G->nblk = (d->batch + G->BT - 1) / G->BT;
-  G->Kq = (d->input_dim + Hp + 3) / 4;
+  G->Kq = (d->input_dim + Hp + 1 + 3) / 4;   // + the ones row that carries the bias
   G->KQ4 = (G->Kq + 3) / 4;
   G->LD = G->BT + ((G->BT % 32 == 0) ? 16 : 0);
   G->wp_floats = (size_t)4 * G->KQ4 * G->TPW * 64 * 4;
-  G->bp_floats = (size_t)4 * G->TPW * 64 * 4;
   G->tape_floats = (size_t)d->seq_len * G->nblk * 4 * G->TPW * G->NT * 5 * 64;
   G->lds_bytes = (size_t)2 * 4 * G->Kq * G->LD * sizeof(float);
   if (G->lds_bytes > 160 * 1024)
@@ -654,41 +718,39 @@ int check_lstm(const hode_lstm_desc* d) {
   return 0;
 }
 
-template <int NT>
-int launch_fwd_tpw(const LstmGeom& G, const LstmArgs& a, hipStream_t s) {
-  const dim3 grid(G.nblk), block(256);
-  switch (G.TPW) {
-    case 3: hipLaunchKernelGGL((hode::lstm_fwd_kernel<NT, 3>), grid, block, G.lds_bytes, s, a); break;
-    case 5: hipLaunchKernelGGL((hode::lstm_fwd_kernel<NT, 5>), grid, block, G.lds_bytes, s, a); break;
-    case 10: hipLaunchKernelGGL((hode::lstm_fwd_kernel<NT, 10>), grid, block, G.lds_bytes, s, a); break;
-  }
+// forward launch geometry: Hp = 160 -> 8 waves x 5 tiles, Hp = 80 -> 4 x 5, Hp = 48 -> 4 x 3
+template <int NT, int TPW, int NW, bool VEC4>
+int launch_fwd_vec(const LstmGeom& G, const LstmArgs& a, hipStream_t s) {
+  if (int e = hode::hip_fail(hipFuncSetAttribute((const void*)hode::lstm_fwd_kernel<NT, TPW, NW, VEC4>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G.lds_bytes),
+                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
+    return e;
+  hipLaunchKernelGGL((hode::lstm_fwd_kernel<NT, TPW, NW, VEC4>), dim3(G.nblk), dim3(64 * NW), G.lds_bytes, s, a);
   return hode::hip_fail(hipGetLastError(), "lstm_fwd launch");
 }
 
-template <int NT, int TPW>
-int set_lds_attr(size_t bytes) {
-  return hode::hip_fail(hipFuncSetAttribute((const void*)hode::lstm_fwd_kernel<NT, TPW>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+template <int NT, int TPW, int NW>
+int launch_fwd_one(const LstmGeom& G, const LstmArgs& a, hipStream_t s) {
+  return (a.OBS & 3) == 0 ? launch_fwd_vec<NT, TPW, NW, true>(G, a, s) : launch_fwd_vec<NT, TPW, NW, false>(G, a, s);
 }
 
 template <int NT>
-int set_lds_attr_tpw(const LstmGeom& G) {
+int launch_fwd_tpw(const LstmGeom& G, const LstmArgs& a, hipStream_t s) {
   switch (G.TPW) {
-    case 3: return set_lds_attr<NT, 3>(G.lds_bytes);
-    case 5: return set_lds_attr<NT, 5>(G.lds_bytes);
-    case 10: return set_lds_attr<NT, 10>(G.lds_bytes);
+    case 3: return launch_fwd_one<NT, 3, 4>(G, a, s);
+    case 5: return launch_fwd_one<NT, 5, 4>(G, a, s);
+    case 10: return launch_fwd_one<NT, 5, 8>(G, a, s);
   }
-  return 0;
+  return hode::fail(HODE_E_UNSUPPORTED, "lstm_fwd: no kernel for %d tiles", G.TPW);
 }
 
 }  // namespace
 
-// workspace: [packed Wcat | packed bias | packed W_hh^T (tape runs only) | tape (tape runs only)]
+// workspace: [packed Wcat (bias row included) | packed W_hh^T (tape runs only) | tape (tape runs only)]
 extern "C" size_t hode_lstm_workspace_bytes(const hode_lstm_desc* d) {
   LstmGeom G;
   if (!d || d->struct_size != sizeof(hode_lstm_desc) || lstm_geom(d, &G, d->save_tape != 0)) return 0;
-  size_t n = align256(G.wp_floats * 4) + align256(G.bp_floats * 4);
+  size_t n = align256(G.wp_floats * 4);
   if (d->save_tape) n += align256(G.whp_floats * 4) + align256(G.tape_floats * 4);
   return n;
 }
@@ -703,21 +765,23 @@ extern "C" int hode_lstm_fwd(const hode_lstm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)d->workspace;
   float* wp = (float*)ws;
-  float* bp = (float*)(ws + align256(G.wp_floats * 4));
-  float* tape = d->save_tape ? (float*)(ws + align256(G.wp_floats * 4) + align256(G.bp_floats * 4) + align256(G.whp_floats * 4)) : nullptr;
-  hipLaunchKernelGGL(hode::lstm_pack_kernel, dim3(256), dim3(256), 0, s, d->w_ih, d->w_hh, d->b_ih, d->b_hh, wp, bp,
-                     d->input_dim, d->hidden_dim, G.TPW, G.KQ4);
+  float* tape = d->save_tape ? (float*)(ws + align256(G.wp_floats * 4) + align256(G.whp_floats * 4)) : nullptr;
+  hipLaunchKernelGGL(hode::lstm_pack_kernel, dim3(256), dim3(256), 0, s, d->w_ih, d->w_hh, d->b_ih, d->b_hh, wp,
+                     d->input_dim, d->hidden_dim, G.TPW == 10 ? 5 : G.TPW, G.TPW == 10 ? 8 : 4, G.KQ4);  // the forward kernel's waves x tiles
   if (int e = hode::hip_fail(hipGetLastError(), "lstm_pack launch")) return e;
   LstmArgs a{};
-  a.x = d->x; a.a = d->a; a.mask = d->mask; a.wp = wp; a.bp = bp; a.h_out = d->h_out; a.c_out = d->c_out; a.tape = tape;
+  a.x = d->x; a.a = d->a; a.mask = d->mask; a.wp = wp; a.h_out = d->h_out; a.c_out = d->c_out; a.tape = tape;
   a.T = d->seq_len; a.B = d->batch; a.OBS = d->obs_dim; a.AD = d->input_dim - d->obs_dim; a.I = d->input_dim;
   a.H = d->hidden_dim; a.Hp = G.Hp; a.Kq = G.Kq; a.KQ4 = G.KQ4; a.LD = G.LD; a.reverse = d->reverse;
+#ifdef HODE_LSTM_STAMPS
+  if (const char* env = getenv("HODE_LSTM_FWD_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(env, nullptr, 0);
+#endif
   int e = 0;
   switch (G.NT) {
-    case 1: e = set_lds_attr_tpw<1>(G); if (!e) e = launch_fwd_tpw<1>(G, a, s); break;
-    case 2: e = set_lds_attr_tpw<2>(G); if (!e) e = launch_fwd_tpw<2>(G, a, s); break;
-    case 3: e = set_lds_attr_tpw<3>(G); if (!e) e = launch_fwd_tpw<3>(G, a, s); break;
-    case 4: e = set_lds_attr_tpw<4>(G); if (!e) e = launch_fwd_tpw<4>(G, a, s); break;
+    case 1: e = launch_fwd_tpw<1>(G, a, s); break;
+    case 2: e = launch_fwd_tpw<2>(G, a, s); break;
+    case 3: e = launch_fwd_tpw<3>(G, a, s); break;
+    case 4: e = launch_fwd_tpw<4>(G, a, s); break;
   }
   return e;
 }
@@ -766,7 +830,7 @@ extern "C" int hode_lstm_bwd(const hode_lstm_desc* d, void* stream) {
     return hode::fail(HODE_E_UNSUPPORTED, "lstm_bwd: tile needs %zu B of LDS (> 160 KiB)", G.lds_bwd_bytes);
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)d->workspace;
-  float* whp = (float*)(ws + align256(G.wp_floats * 4) + align256(G.bp_floats * 4));
+  float* whp = (float*)(ws + align256(G.wp_floats * 4));
   const float* tape = (const float*)((char*)whp + align256(G.whp_floats * 4));
   hipLaunchKernelGGL(hode::lstm_pack_hh_kernel, dim3(128), dim3(256), 0, s, d->w_hh, whp, d->hidden_dim, G.TPW);
   if (int e = hode::hip_fail(hipGetLastError(), "lstm_pack_hh launch")) return e;
