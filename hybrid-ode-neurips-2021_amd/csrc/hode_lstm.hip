@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
     HODE_FSTAMP(1)
 
     // cell update: lane (g, pc) holds gates i,f,g,o of unit u = (w*TPW + tt)*4 + g for patient 16c + pc
+    float* nxt_lane = nxt + (p.I + w * TPW * 4 + g) * LD + pc;   // lane base; tile / column offsets are immediates
     float* tp = p.tape ? p.tape + (((size_t)t * gridDim.x + blockIdx.x) * NW + w) * TPW * NT * 5 * 64 : nullptr;  // wave-uniform
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
         const float cn = __builtin_fmaf(gf, cst[tt][c], gi * gg);
         const float hn = go * tanh_f32(cn);
         cst[tt][c] = cn;
-        nxt[(size_t)(p.I + u) * LD + 16 * c + pc] = hn;
+        nxt_lane[4 * tt * LD + 16 * c] = hn;
         if (tp) {
           float* q5 = tp + (tt * NT + c) * 5 * 64;
           q5[l] = gi; q5[64 + l] = gf; q5[128 + l] = gg; q5[192 + l] = go; q5[256 + l] = cn;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
 // The four partial [H x BT] results are exchanged through LDS slabs and summed in a fixed order.
 struct LstmBwdArgs {
   const float* __restrict__ tape;      // forward tape [T][nblk][4][TPW][NT][5][64]
-  const float* __restrict__ whp;       // packed W_hh^T fragments [4][TPW(tau)][TPW(mt)][64][4]
+  const float* __restrict__ whp;       // packed W_hh^T fragments [4][TPW(tau)][4 (gate row)][ceil(TPW/4)][64][4 (mt)]
   const float* __restrict__ grad_h_out;  // [B][H]
   float* __restrict__ grad_gates;      // [T][B][4H]
   float* __restrict__ h_prev;          // GEMM operand [T][B][W]: (OBS columns left to the caller: x*mask) | action columns
@@ -385,18 +386,24 @@ struct LstmBwdArgs {
   unsigned long long* dbg;  // HODE_LSTM_STAMPS builds only: [T][8] s_memtime stamps of wave 0 of block 0
 };
 
+// W_hh^T fragments, one 16-byte group per (wave, contracted tile tau, gate row r, group j of 4 output tiles, lane):
+// element i of the group is the A-operand value of output tile mt = 4j + i.  Gate-row-major so that the kernel streams
+// 4 * ceil(TPW/4) registers per 30-MFMA block instead of holding all 4 * TPW of a tile.
 __global__ void lstm_pack_hh_kernel(const float* __restrict__ w_hh, float* __restrict__ whp, int H, int TPW) {
-  const long long n = 4LL * TPW * TPW * 64 * 4;
+  const int MG = (TPW + 3) / 4;
+  const long long n = 4LL * TPW * 4 * MG * 64 * 4;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
-    const int r = idx & 3;
+    const int i = idx & 3;
     const int l = (idx >> 2) & 63;
     long long q = idx >> 8;
-    const int mt = (int)(q % TPW); q /= TPW;
+    const int j = (int)(q % MG); q /= MG;
+    const int r = (int)(q & 3); q >>= 2;
     const int tau = (int)(q % TPW);
     const int w = (int)(q / TPW);
+    const int mt = 4 * j + i;
     const int u = (w * TPW + tau) * 4 + (l >> 4);   // contracted unit (its gate r)
     const int uo = 16 * mt + (l & 15);              // output unit
-    whp[idx] = (u < H && uo < H) ? w_hh[((size_t)r * H + u) * H + uo] : 0.f;
+    whp[idx] = (mt < TPW && u < H && uo < H) ? w_hh[((size_t)r * H + u) * H + uo] : 0.f;
   }
 }
 
@@ -412,10 +419,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int g = l >> 4, pc = l & 15;
   const int b0 = blockIdx.x * BT;
   const int nvalid = min(BT, p.B - b0);
-  const int LD = p.LD;
+  constexpr int LD = BT + ((BT % 32 == 0) ? 16 : 0);   // == p.LD (lstm_geom); compile-time: slab offsets become immediates
   float* dgt = lds;                      // [BT][LDG]   (time-shared with the partial slabs [4][Hp][LD])
   float* slab = lds;
   float* hT = lds + (size_t)BT * LDG;    // [BT][LDH]
+  const int unit0 = __builtin_amdgcn_readfirstlane(w) * TPW * 4 + g;   // the lane's unit in tile 0 of its wave
+  float* dg_lane = dgt + pc * LDG + unit0;
+  float* hT_lane = hT + pc * LDH + unit0;
+  float* slab_w = slab + (__builtin_amdgcn_readfirstlane(w) * Hp + 4 * g) * LD + pc;   // partial of wave w, rows 4g.., column pc
+  const float* slab_r = slab + unit0 * LD + pc;
   const int H = p.H;
 
   float carry_h[TPW][NT], carry_c[TPW][NT];
@@ -434,37 +446,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const size_t tape_step = (size_t)gridDim.x * 4 * TPW * NT * 5 * 64;
   const size_t tape_blk = ((size_t)blockIdx.x * 4 + wu) * TPW * NT * 5 * 64;
-  const f32x4* whb = reinterpret_cast<const f32x4*>(p.whp) + (size_t)wu * TPW * TPW * 64;
+  constexpr int MG = (TPW + 3) / 4;   // 16-byte weight groups per (tile, gate row)
+  const f32x4* whb = reinterpret_cast<const f32x4*>(p.whp) + (size_t)wu * TPW * 4 * MG * 64;
 
   // Operands of one (step, unit tile): the step's activated gates and cell state and the previous step's cell state
-  // and output gate for NT patient columns, plus the TPW weight fragments the tile's MFMAs read.  They are fetched ONE
-  // TILE AHEAD into the other register set (the tile loop is fully unrolled, so the sets alternate by renaming): a load
-  // that is consumed by the next instruction costs an HBM / L2 round trip per tile, which is what bound this kernel
-  // (10 tiles x 3 serial waits per step, 61 us per step against 16 us of MFMA time).
+  // and output gate for NT patient columns (TapeOps), and the TPW weight fragments the tile's MFMAs read.
+  //
+  // Software pipeline over the unit tiles of a step (fully unrolled, register sets alternate by renaming):
+  //   body(tt) = [tape loads of tile tt+2] [weight loads of tile tt+1] [element-wise step of tile tt+1] [MFMAs of tile tt]
+  // The element-wise step of the NEXT tile and the matrix products of THIS one are independent and sit in one basic
+  // block, interleaved one VALU group per MFMA: with one wave per SIMD nothing else fills the matrix pipe while the
+  // wave does VALU work (26 us per step for 16 us of MFMA time when each tile ran element-wise -> MFMAs in sequence).
+  // A load consumed by the next instruction costs an HBM / L2 round trip per tile, hence the two-tile tape distance.
   struct TapeOps { float gi[NT], gf[NT], gg[NT], go[NT], cn[NT], cp[NT], op[NT]; };
+  // All tape and weight loads are BUFFER loads: 4-SGPR resource (rebuilt per step with scalar instructions) + one lane
+  // offset register + scalar / immediate offsets.  With global loads the compiler kept one 64-bit VGPR address per 4 KiB
+  // window (19 pairs) and, behind the pointer laundering that stops it hoisting 100 fragment addresses, fell back to
+  // FLAT loads for the weights (they count on lgkmcnt as well as vmcnt: a wait for an LDS write became a wait for L2).
+  auto rsrc_of = [](const void* ptr) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, 0x7fffffff, 0x00020000);  // raw, dword format
+  };
+  auto ldf = [&](__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, l * 4, byte_off, 0));
+  };
   auto step_ptrs = [&](int s, const float*& tc, const float*& tpv) {
     const int t = p.reverse ? p.T - 1 - s : s;
     const int t_prev = p.reverse ? t + 1 : t - 1;  // time index processed one step earlier in the forward sweep
     tc = p.tape + (size_t)t * tape_step + tape_blk;
     tpv = (s > 0) ? p.tape + (size_t)t_prev * tape_step + tape_blk : tc;  // s == 0: dummy reads, masked by has_prev
   };
-  auto load_ops = [&](TapeOps& o, f32x4 (&wf)[TPW], const f32x4* wh, const float* tc, const float* tpv, int tt) {
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      const float* q5 = tc + (tt * NT + c) * 5 * 64;   // uniform
-      const float* p5 = tpv + (tt * NT + c) * 5 * 64;
-      o.gi[c] = q5[l]; o.gf[c] = q5[64 + l]; o.gg[c] = q5[128 + l]; o.go[c] = q5[192 + l]; o.cn[c] = q5[256 + l];
-      o.cp[c] = p5[256 + l]; o.op[c] = p5[192 + l];
-    }
-#pragma unroll
-    for (int mt = 0; mt < TPW; ++mt) wf[mt] = (wh + (tt * TPW + mt) * 64)[l];
+  auto load_tape_col = [&](TapeOps& o, __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rp, int tt, int c) {
+    const int q5 = (tt * NT + c) * 5 * 64 * 4;   // byte offset of the (tile, column) record: [gi | gf | gg | go | c][64]
+    o.gi[c] = ldf(rc, q5); o.gf[c] = ldf(rc, q5 + 256); o.gg[c] = ldf(rc, q5 + 512); o.go[c] = ldf(rc, q5 + 768);
+    o.cn[c] = ldf(rc, q5 + 1024);
+    o.cp[c] = ldf(rp, q5 + 1024); o.op[c] = ldf(rp, q5 + 768);
   };
-  TapeOps oa, ob;
-  f32x4 wa[TPW], wb[TPW];
+  auto load_tape = [&](TapeOps& o, __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rp, int tt) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) load_tape_col(o, rc, rp, tt, c);
+  };
+  const __amdgpu_buffer_rsrc_t wrs = rsrc_of(whb);
+  // weights of row block R = 4 * tile + gate row
+  auto load_w = [&](f32x4 (&wf)[MG], int R) {
+#pragma unroll
+    for (int j = 0; j < MG; ++j)
+      wf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, l * 16, (R * MG + j) * 64 * 16, 0));
+  };
+  TapeOps ops[2];          // tile tt lives in ops[tt & 1]: during body(tt) the sets hold tiles tt+1 (consumed) and tt+2 (in flight)
+  f32x4 wfr[3][MG];        // row block R = 4 tt + r in wfr[R % 3], loaded two blocks (60 NT/3 MFMAs) ahead
+  float dgr[2][NT][4];     // tile tt's gate cotangents (the MFMA B operands) in dgr[tt & 1]
   {
     const float *tc0, *tpv0;
     step_ptrs(p.T - 1, tc0, tpv0);
-    load_ops(oa, wa, whb, tc0, tpv0, 0);
+    load_tape(ops[0], rsrc_of(tc0), rsrc_of(tpv0), 0);
+    load_tape(ops[1], rsrc_of(tc0), rsrc_of(tpv0), TPW > 1 ? 1 : 0);
+    load_w(wfr[0], 0);
+    load_w(wfr[1], 1);
   }
 
 #ifdef HODE_LSTM_STAMPS
@@ -477,12 +514,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     HODE_LSTAMP(0)
     const float *tc, *tpv, *tc_n, *tpv_n;
     step_ptrs(s, tc, tpv);
-    step_ptrs(s > 0 ? s - 1 : 0, tc_n, tpv_n);  // next step's first tile (s == 0: a harmless repeat)
+    step_ptrs(s > 0 ? s - 1 : 0, tc_n, tpv_n);  // next step's first tiles (s == 0: a harmless repeat)
     const float has_prev = s > 0 ? 1.0f : 0.0f;
-    // re-materialise the (SGPR) weight base every step: otherwise the TPW * TPW fragment addresses are hoisted out of
-    // the step loop as per-lane 64-bit pointers, spilled, and reloaded with a wait in front of every load
-    const f32x4* wh = whb;
-    asm volatile("" : "+s"(wh));
+    const __amdgpu_buffer_rsrc_t rs_c = rsrc_of(tc), rs_p = rsrc_of(tpv), rs_cn = rsrc_of(tc_n), rs_pn = rsrc_of(tpv_n);
 
     f32x4 acc[TPW][NT];
 #pragma unroll
@@ -508,11 +542,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
 
-    auto tile = [&](int tt, const TapeOps& o, const f32x4 (&wf)[TPW], TapeOps& o_nx, f32x4 (&wf_nx)[TPW]) {
-      if (tt + 1 < TPW) load_ops(o_nx, wf_nx, wh, tc, tpv, tt + 1);
-      else load_ops(o_nx, wf_nx, wh, tc_n, tpv_n, 0);
-      const int u = (w * TPW + tt) * 4 + g;
-      float dgr[NT][4];
+    // element-wise step of tile tt: gate cotangents -> dgr[tt & 1] (+ the transposed copies for the row-major stores)
+    auto elementwise = [&](int tt, const TapeOps& o, float (&dg)[NT][4]) {
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
         const float gi = o.gi[c], gf = o.gf[c], gg = o.gg[c], go = o.go[c], cn = o.cn[c];
@@ -521,36 +552,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float tcn = tanh_f32(cn);
         const float dh = carry_h[tt][c];
         const float dc = __builtin_fmaf(dh * go, __builtin_fmaf(-tcn, tcn, 1.0f), carry_c[tt][c]);
-        dgr[c][0] = dc * gg * gi * (1.0f - gi);
-        dgr[c][1] = dc * c_prev * gf * (1.0f - gf);
-        dgr[c][2] = dc * gi * __builtin_fmaf(-gg, gg, 1.0f);
-        dgr[c][3] = dh * tcn * go * (1.0f - go);
+        dg[c][0] = dc * gg * gi * (1.0f - gi);
+        dg[c][1] = dc * c_prev * gf * (1.0f - gf);
+        dg[c][2] = dc * gi * __builtin_fmaf(-gg, gg, 1.0f);
+        dg[c][3] = dh * tcn * go * (1.0f - go);
         carry_c[tt][c] = dc * gf;
-        const int b = 16 * c + pc;
-        if (u < Hp) {  // always true (u < 16 TPW); kept: without the branch the scheduler merges the ten tiles into one block and
-                       // the tile loop takes 47 us instead of 26 (measured, tools/lstm_stamp_probe.py)
+        // lane base + compile-time offset: (patient 16c + pc, unit (w TPW + tt) 4 + g).  Written as one index
+        // expression the compiler hoisted one address per (tile, column, gate) out of the step loop and spilled them.
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dgt[(size_t)b * LDG + r * Hp + u] = dgr[c][r];
-          hT[(size_t)b * LDH + u] = h_prev;
-        }
+        for (int r = 0; r < 4; ++r) dg_lane[16 * c * LDG + r * Hp + 4 * tt] = dg[c][r];
+        hT_lane[16 * c * LDH + 4 * tt] = h_prev;
       }
+    };
+    // body(tt): row block r of the tile = TPW * NT MFMAs.  The tape operands of tile tt + 2 are requested in the first
+    // MFMAs of the body (they are needed from the start of the next body: one body = 1.6 us of latency cover), the
+    // weights of row block R + 2 at the start of row block R; the group barriers below pin that issue order (left to
+    // itself the scheduler sinks every load next to its use, and an in-order vmcnt wait on the newest load waits for all).
+    auto body = [&](int tt) {
+      TapeOps& o_nx = ops[tt & 1];
+      const bool same_step = tt + 2 < TPW;
+      const int tile_nx = same_step ? tt + 2 : min(tt + 2 - TPW, TPW - 1);
+      load_w(wfr[(4 * tt + 2) % 3], (4 * tt + 2) % (4 * TPW));
+      if (same_step) load_tape(o_nx, rs_c, rs_p, tile_nx);
+      else load_tape(o_nx, rs_cn, rs_pn, tile_nx);
+      if (tt + 1 < TPW) elementwise(tt + 1, ops[(tt + 1) & 1], dgr[(tt + 1) & 1]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+        const int R = 4 * tt + r;
+        if (r > 0) load_w(wfr[(R + 2) % 3], (R + 2) % (4 * TPW));   // past the step's last block: the next step's first two
 #pragma unroll
         for (int mt = 0; mt < TPW; ++mt)
 #pragma unroll
           for (int c = 0; c < NT; ++c)
-            acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[mt][r], dgr[c][r], acc[mt][c], 0, 0, 0);
+            acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[R % 3][mt >> 2][mt & 3], dgr[tt & 1][c][r], acc[mt][c], 0, 0, 0);
+      }
+      // issue pipeline of the block: per MFMA one or two VALU of the next tile's element-wise step, the loads in the
+      // first MFMAs of each row block, one LDS write every 8 MFMAs
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        constexpr int MF = TPW * NT;
+        const int n_loads = MG + (r == 0 ? 7 * NT : 0);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // 1 MFMA
+          if (i < n_loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // 1 VMEM read
+          if (tt + 1 < TPW) {
+            if (i & 1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                 // 1 VALU
+            else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                       // 2 VALU
+            if ((i & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // 1 LDS write
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     };
+    elementwise(0, ops[0], dgr[0]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
-      if (tt & 1) tile(tt, ob, wb, oa, wa);
-      else tile(tt, oa, wa, ob, wb);
+    for (int tt = 0; tt < TPW; ++tt) body(tt);
+    // canonical register sets for the next step: its tile 0 -> ops[0], its tile 1 -> ops[1], its row blocks 0, 1 ->
+    // wfr[0], wfr[1]
+    if constexpr (TPW & 1) {
+      const TapeOps t0 = ops[1], t1 = ops[0];
+      ops[0] = t0; ops[1] = t1;
     }
-    if constexpr (TPW & 1) {  // odd tile count: the next step's first tile landed in the other set
-      oa = ob;
+    if constexpr ((4 * TPW) % 3 != 0) {
+      f32x4 n0[MG], n1[MG];
 #pragma unroll
-      for (int mt = 0; mt < TPW; ++mt) wa[mt] = wb[mt];
+      for (int j = 0; j < MG; ++j) { n0[j] = wfr[(4 * TPW) % 3][j]; n1[j] = wfr[(4 * TPW + 1) % 3][j]; }
+#pragma unroll
+      for (int j = 0; j < MG; ++j) { wfr[0][j] = n0[j]; wfr[1][j] = n1[j]; }
     }
     HODE_LSTAMP(1)
     __syncthreads();
@@ -621,17 +691,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int c = 0; c < NT; ++c)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-          slab[((size_t)w * Hp + 16 * mt + 4 * g + rr) * LD + 16 * c + pc] = acc[mt][c][rr];
+          slab_w[(16 * mt + rr) * LD + 16 * c] = acc[mt][c][rr];
     HODE_LSTAMP(5)
     __syncthreads();
     HODE_LSTAMP(6)
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-      const int u = (w * TPW + tt) * 4 + g;
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
-        const float* sp = slab + (size_t)u * LD + 16 * c + pc;
-        carry_h[tt][c] = ((sp[0] + sp[(size_t)Hp * LD]) + sp[(size_t)2 * Hp * LD]) + sp[(size_t)3 * Hp * LD];
+        const float* sp = slab_r + 4 * tt * LD + 16 * c;
+        carry_h[tt][c] = ((sp[0] + sp[Hp * LD]) + sp[2 * Hp * LD]) + sp[3 * Hp * LD];
       }
     }
     HODE_LSTAMP(7)
@@ -694,7 +763,7 @@ int lstm_geom(const hode_lstm_desc* d, LstmGeom* G, bool bwd_compatible) {
   G->LD = G->BT + ((G->BT % 32 == 0) ? 16 : 0);
   G->tape_floats = (size_t)d->seq_len * G->nblk * 4 * G->TPW * G->NT * 5 * 64;
   G->lds_bytes = (size_t)2 * 4 * G->Kq * G->LD * sizeof(float);
-  G->whp_floats = (size_t)4 * G->TPW * G->TPW * 64 * 4;
+  G->whp_floats = (size_t)4 * G->TPW * 4 * ((G->TPW + 3) / 4) * 64 * 4;
   {
     const size_t tile = (size_t)G->BT * (4 * Hp + 4), slabs = (size_t)4 * Hp * G->LD;
     G->lds_bwd_bytes = ((tile > slabs ? tile : slabs) + (size_t)G->BT * (Hp + 4)) * sizeof(float);
