@@ -569,6 +569,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // weights of row block R + 2 at the start of row block R; the group barriers below pin that issue order (left to
     // itself the scheduler sinks every load next to its use, and an in-order vmcnt wait on the newest load waits for all).
     auto body = [&](int tt) {
+#ifdef HODE_LSTM_STAMPS
+      if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[(size_t)(p.T + s) * 16 + tt] = __builtin_amdgcn_s_memtime();  // no wait
+#endif
       TapeOps& o_nx = ops[tt & 1];
       const bool same_step = tt + 2 < TPW;
       const int tile_nx = same_step ? tt + 2 : min(tt + 2 - TPW, TPW - 1);

@@ -5,12 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
 from hode.lstm import lstm_encode
 dev = torch.device("cuda:0")
-T, B, obs, H = 100, 10000, 80, 160
+T, B, obs, H = 100, int(os.environ.get("PROBE_B", "10000")), 80, 160   # PROBE_B=144: three blocks, the tape stays in cache (isolates memory latency)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(T, B, obs, generator=g).to(dev); a = torch.rand(T, B, 1, generator=g).to(dev)
 m = (torch.rand(T, B, obs, generator=g) < 0.5).float().to(dev)
 lstm = torch.nn.LSTM(obs + 1, H).to(dev)
-dbg = torch.zeros(T * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(T * 8 + 2 * T * 16, dtype=torch.int64, device=dev)
 os.environ["HODE_LSTM_DBG_PTR"] = hex(dbg.data_ptr())
 dbgf = torch.zeros(T * 8 + 2 * T * 16, dtype=torch.int64, device=dev)
 os.environ["HODE_LSTM_FWD_DBG_PTR"] = hex(dbgf.data_ptr())
@@ -20,7 +20,10 @@ for _ in range(2):
     h = lstm_encode(x, a, m, *prm, reverse=True)
     h.sum().backward()
 torch.cuda.synchronize()
-s = dbg.cpu().numpy().reshape(T, 8)[5:95]
+allb = dbg.cpu().numpy()
+s = allb[:T * 8].reshape(T, 8)[5:95]
+body = allb[T * 16: 2 * T * 16].reshape(T, 16)[5:95].astype(np.int64)
+print('BPTT tile bodies, cycles (120 MFMAs = 3840 when the pipe never waits): first body starts %d after the step stamp;' % int(np.median(body[:, 0] - s[:, 0].astype(np.int64))), np.median(np.diff(body[:, :10], axis=1), axis=0).astype(int).tolist(), '; last body + tail', int(np.median(s[:, 1].astype(np.int64) - body[:, 9])))
 d = np.diff(s, axis=1)
 names = ["tile loop (elementwise + 1200 MFMAs + LDS transposes)", "barrier", "store phase (dG, h_prev rows)", "barrier", "slab write", "barrier", "carry_h read"]
 for n, v in zip(names, np.median(d, axis=0)): print("%-58s %7d cycles  %.2f us" % (n, v, v / 2400.0))
