@@ -407,6 +407,9 @@ __global__ void lstm_pack_hh_kernel(const float* __restrict__ w_hh, float* __res
   }
 }
 
+#ifndef HODE_BPTT_BURST
+#define HODE_BPTT_BURST 1   // 1: element-wise burst, then the MFMAs with only loads between them; 0: 1 MFMA : 1-2 VALU interleave (3 % slower, tools/micro/mfma_valu_overlap.hip)
+#endif
 template <int NT, int TPW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(LstmBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -579,6 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (same_step) load_tape(o_nx, rs_c, rs_p, tile_nx);
       else load_tape(o_nx, rs_cn, rs_pn, tile_nx);
       if (tt + 1 < TPW) elementwise(tt + 1, ops[(tt + 1) & 1], dgr[(tt + 1) & 1]);
+      if (HODE_BPTT_BURST) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int R = 4 * tt + r;
@@ -594,12 +598,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         constexpr int MF = TPW * NT;
-        const int n_loads = MG + (r == 0 ? 7 * NT : 0);
+        const int n_loads = HODE_BPTT_BURST ? (r == 0 ? 0 : MG) : MG + (r == 0 ? 7 * NT : 0);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // 1 MFMA
           if (i < n_loads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // 1 VMEM read
-          if (tt + 1 < TPW) {
+          if (tt + 1 < TPW && !HODE_BPTT_BURST) {
             if (i & 1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                 // 1 VALU
             else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                       // 2 VALU
             if ((i & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // 1 LDS write
