@@ -34,6 +34,46 @@ def test_loss_and_gradients(D, obs, T, B):
         assert rel <= 2e-5, rel
 
 
+@pytest.mark.parametrize("D,obs,T,B", [(12, 80, 9, 21), (12, 72, 3, 50), (12, 52, 2, 16), (8, 40, 6, 19), (8, 48, 4, 31), (8, 36, 2, 7)])
+def test_matrix_core_variant_edges(D, obs, T, B):
+    """The matrix-core kernel (D = 12 / 48 < obs <= 80, D = 8 / 32 < obs <= 48): partial last output tile, row counts that
+    are not a multiple of 16, general (non 0/1) masks, the loss-only launch, and agreement with the lane-per-4-outputs
+    kernel (HODE_READOUT_VALU) on the same inputs."""
+    import os
+    from hode.readout import masked_sse_readout
+    dev = _dev()
+    gen = torch.Generator().manual_seed(obs + B)
+    h = torch.randn(T, B, D, generator=gen)
+    x = torch.randn(T, B, obs, generator=gen)
+    m = torch.rand(T, B, obs, generator=gen) * (torch.rand(T, B, obs, generator=gen) < 0.6).float()
+    lin = torch.nn.Linear(D, obs)
+    hr = h.clone().double().requires_grad_(True)
+    w64, b64 = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    ref = torch.sum((x.double() - (hr @ w64.t() + b64)) ** 2 * m.double()) / B
+    ref.backward()
+
+    def run():
+        hg = h.to(dev).requires_grad_(True)
+        wg, bg = lin.weight.detach().to(dev).requires_grad_(True), lin.bias.detach().to(dev).requires_grad_(True)
+        lik = masked_sse_readout(hg, x.to(dev), m.to(dev), wg, bg)
+        lik.backward()
+        with torch.no_grad():
+            lik0 = masked_sse_readout(hg.detach(), x.to(dev), m.to(dev), wg.detach(), bg.detach())
+        return lik.item(), lik0.item(), hg.grad.cpu().double(), wg.grad.cpu().double(), bg.grad.cpu().double()
+
+    got = run()
+    os.environ["HODE_READOUT_VALU"] = "1"
+    try:
+        alt = run()
+    finally:
+        del os.environ["HODE_READOUT_VALU"]
+    for res in (got, alt):
+        assert abs(res[0] - ref.item()) <= 2e-5 * abs(ref.item())
+        assert abs(res[1] - ref.item()) <= 2e-5 * abs(ref.item())
+        for g, want in zip(res[2:], (hr.grad, w64.grad, b64.grad)):
+            assert float((g - want).norm() / want.norm()) <= 2e-5
+
+
 def test_vi_loss_uses_fused_path_and_matches_unfused():
     import model
     from hode import synth
