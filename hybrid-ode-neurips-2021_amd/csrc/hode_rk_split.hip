@@ -444,6 +444,12 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   // Dose(t_s) [0..3] and dDose/dkel [4..7] of the 4 stages; written by the expert wave when it re-integrates, by the
   // learned waves (stage q by quad lane q) when the stage states come from the tape
   __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][8];
+  // THW: the 13 (15) theta-gradient accumulations of every stage run on a FIFTH wave, one iteration behind the expert wave
+  // and off its cotangent chain (they are 40 % of its instructions, two v_log per stage among them): the expert wave hands
+  // over the stage cotangents g_s through gring, the theta wave reads the stage states from the forward's tape and forms
+  // the doses itself.  Only with the tape (without it the stage states exist nowhere but in the expert wave).
+  constexpr bool THW = TAPE && NEED_TH;
+  __shared__ __attribute__((aligned(16))) float gring[2][4][kSplitPatients + 1][4];   // row kSplitPatients: zeros
   // epilogue: the 4 per-row (16-lane) partial sums of every gradient entry of a wave, summed across rows from here
   __shared__ float red[4][4][M * D + M];
   extern __shared__ float tg[];  // time grid, see sp_stage_grid
@@ -565,7 +571,10 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         sp_adjoint_step<METHOD>(lam, dt, [&](int s, const F4& gs) {
           const float g[4] = {gs.a.x, gs.a.y, gs.b.x, gs.b.y};
           float av[4];
-          roche_vjp<4, 1, ABLATE, HILL2, NEED_TH>(th, none, nonec, ln_ec50, dv[s], Y[s], own1, g, 0, av, acc);
+          if constexpr (THW) {
+            if (mine) *reinterpret_cast<float4*>(&gring[par ^ 1][s][slot][0]) = make_float4(g[0], g[1], g[2], g[3]);
+          }
+          roche_vjp<4, 1, ABLATE, HILL2, NEED_TH && !THW>(th, none, nonec, ln_ec50, dv[s], Y[s], own1, g, 0, av, acc);
           F4 r = cs[s];
           r.a += pair2(av[0], av[1]);
           r.b += pair2(av[2], av[3]);
@@ -585,9 +594,72 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     }
     if (live) *reinterpret_cast<float4*>(a.grad_y0 + (size_t)p * D) = make_float4(lam.a.x, lam.a.y, lam.b.x, lam.b.y);
     // theta partials: 16-lane row sums by DPP rotations, the 4 rows joined through LDS (in-order within the wave)
+    if constexpr (!THW) {
+#pragma unroll
+      for (int i = 0; i < kNTheta; ++i) {
+        const float v = row_sum(NEED_TH ? acc.dth[i] : 0.f);
+        if ((lane & 15) == 0) red[0][lane >> 4][i] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (lane < kNTheta)
+        a.part_th[(size_t)blockIdx.x * kNTheta + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    }
+  } else if (THW && wave == 4) {
+    // ================================================================== theta wave (one patient per lane, like the expert wave)
+    const int slot = lane < kSplitPatients ? lane : 0;
+    const bool mine = lane < kSplitPatients;
+    const int p = min(b0 + slot, a.B - 1);
+    const int gslot = mine ? lane : kSplitPatients;   // spare lanes read the zero row: their contributions are exactly zero
+    DoseSched<K1> ds;
+    ds.dosage = a.dosage[p];
+    ds.K = a.K;
+    ds.taus = a.dose_times + (size_t)p * a.K;
+    ds.tau0 = K1 ? ds.taus[0] : 0.f;
+    const float ln_ec50 = log_f32(th.ec50);
+    if (lane < 32) (&gring[lane >> 4][(lane >> 2) & 3][kSplitPatients][0])[lane & 3] = 0.f;
+    const unsigned lane_h = (unsigned)p * D, lane_t = (unsigned)p * 4;
+    float dth[kNTheta];
+#pragma unroll
+    for (int i = 0; i < kNTheta; ++i) dth[i] = 0.f;
+    float tp[4][4];  // stage states of the step to be processed next (from h and the forward's tape)
+    auto fetch = [&](int m) {
+      const float4 v = *reinterpret_cast<const float4*>(a.h + (size_t)m * row + lane_h);
+      tp[0][0] = v.x; tp[0][1] = v.y; tp[0][2] = v.z; tp[0][3] = v.w;
+      const float* __restrict__ tape_m = a.tape + (size_t)m * (NS - 1) * a.B * 4;
+#pragma unroll
+      for (int s = 1; s < NS; ++s) {
+        const float4 u = *reinterpret_cast<const float4*>(tape_m + ((unsigned)(s - 1) * (unsigned)a.B * 4u + lane_t));
+        tp[s][0] = u.x; tp[s][1] = u.y; tp[s][2] = u.z; tp[s][3] = u.w;
+      }
+    };
+    // the theta terms of step m; stages in the order the expert wave's adjoint visits them (3, 2, 1, 0), so that every
+    // accumulator sees its terms in the same order as when the expert wave accumulates them itself
+    auto theta_step = [&](int m, int gpar) {
+      const float t0 = tg[m], t1 = tg[m + 1];
+#pragma unroll
+      for (int si = 0; si < NS; ++si) {
+        const int s = NS - 1 - si;
+        const float4 gv = *reinterpret_cast<const float4*>(&gring[gpar][s][gslot][0]);
+        const DoseVal dv = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, METHOD == HODE_METHOD_MIDPOINT && s == 1 ? 1 : (METHOD == HODE_METHOD_RK4_38 ? s : 0)), th.kel);
+        const float g[4] = {gv.x, gv.y, gv.z, gv.w};
+        roche_theta_grad<ABLATE, HILL2>(th, ln_ec50, dv, tp[s], g, dth);
+      }
+    };
+    __syncthreads();  // the expert wave's prologue
+    auto t_iter = [&](int k, auto PAR) {
+      constexpr int gpar = decltype(PAR)::value;  // == (k - 1) & 1: what the expert wave wrote in iteration k - 1
+      if (k >= 2) theta_step(T - k, gpar);
+      if (k >= 1 && T - k - 1 >= 0) fetch(T - k - 1);
+      __syncthreads();
+    };
+    for (int k = 0; k < T; k += 2) {
+      t_iter(k, IC<1>{});
+      if (k + 1 < T) t_iter(k + 1, IC<0>{});
+    }
+    if (T >= 2) theta_step(0, (T - 1) & 1);
 #pragma unroll
     for (int i = 0; i < kNTheta; ++i) {
-      const float v = row_sum(NEED_TH ? acc.dth[i] : 0.f);
+      const float v = row_sum(dth[i]);
       if ((lane & 15) == 0) red[0][lane >> 4][i] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -768,8 +840,9 @@ __global__ __launch_bounds__(64) void split_fold_kernel(const float* __restrict_
   *dst = overwrite ? s : *dst + s;
 }
 
+// 4 waves (expert + 3 learned) or, with the tape and theta gradients, 5 (+ the theta wave, which shares a SIMD)
 template <int D, int METHOD, bool ABLATE, bool NEED_TH, bool TAPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_bwd_kernel(SplitBwdArgs a) {
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) void split_bwd_kernel(SplitBwdArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
   if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true, TAPE>(a);
   else if (hill2) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, false, TAPE>(a);
@@ -813,7 +886,7 @@ int split_bwd_method(const hode_solve_desc* d, const hode::SplitBwdArgs& a, hipS
   const size_t lds = (size_t)(d->n_times + 3) * sizeof(float);  // the time grid (n_times <= kSplitMaxT)
 #define HODE_SPLIT_BWD(M)                                                                                        \
   if (d->need_theta_grad) {                                                                                      \
-    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, true>), grid, block, lds, s, a);    \
+    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, true>), grid, dim3(320), lds, s, a); \
     else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, false>), grid, block, lds, s, a);          \
   } else {                                                                                                       \
     if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, true>), grid, block, lds, s, a);   \

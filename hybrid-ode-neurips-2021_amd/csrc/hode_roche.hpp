@@ -296,4 +296,39 @@ HODE_DEV void roche_vjp(const RocheTheta& th, const MlSlice<D, LPP>& ml, const M
   }
 }
 
+// The parameter-gradient half of roche_vjp's expert block on its own (same expressions, same order): the split layout's
+// adjoint runs it on a separate wave, off the cotangent chain (hode_rk_split.hip).
+template <bool ABLATE, bool HILL2>
+HODE_DEV void roche_theta_grad(const RocheTheta& th, float ln_ec50, DoseVal dose, const float (&Y)[4], const float (&g)[4],
+                               float (&dth)[kNTheta]) {
+  const float dis = Y[0], ir = Y[1], imm = Y[2], d2 = Y[3];
+  const float g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+  if constexpr (!ABLATE) {
+    const float immp = pow_hill<HILL2>(imm, th.hc);
+    const float irp = pow_hill<HILL2>(ir, th.hp);
+    const float ecp = pow_hill<HILL2>(th.ec50, th.hp);
+    const float rden = __builtin_amdgcn_rcpf(ecp + irp);
+    const float g0d = g0 * dis, g1d = g1 * dis, g1i = g1 * ir;
+    const float er2 = th.emax * rden * rden;  // emax / (E + P)^2
+    dth[0] -= g0d * th.kci * dpow_dp(imm, th.hc, immp);
+    const float dP = dpow_dp(ir, th.hp, irp);
+    const float dE = (th.ec50 == 0.0f && th.hp >= 0.0f) ? 0.0f : ecp * ln_ec50;
+    dth[1] += g1 * er2 * (dP * ecp - irp * dE);
+    dth[2] -= g1 * er2 * irp * dpow_dx<HILL2>(th.ec50, th.hp);
+    dth[3] += g1 * irp * rden;
+    dth[4] -= g1i * d2;
+    dth[5] -= g0d * ir;
+    dth[6] -= g0d * immp;
+    dth[7] += g0d;
+    dth[8] += g1d;
+    dth[9] += g1d * ir;
+    dth[10] -= g1i;
+    dth[11] += g2 * ir;
+    dth[12] += g3 * ((dose.v - d2) + th.kel * dose.dk);
+  } else {
+    dth[13] -= dis * g1;
+    dth[14] -= imm * g3;
+  }
+}
+
 }  // namespace hode
