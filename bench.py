@@ -678,7 +678,7 @@ def main():
         if not args.no_tape:
             # deliberate recompute <-> traffic trade: the forward leaves the 3 intermediate expert stage
             # states of every step (16 B each) and the backward reads them back instead of re-integrating
-            out["roofline"]["tape_bytes_per_launch"] = (T - 1) * 3 * N_PER_GPU * 16
+            out["roofline"]["tape_bytes_per_launch"] = (T - 1) * 3 * N_PER_GPU * 16 + (T - 1) * N_PER_GPU * (D - 4) * 2 * 4  # expert stage states + 2 learned stage derivatives
             out["config"]["stage_tape"] = True
         if cpu:
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(prob, gpu)

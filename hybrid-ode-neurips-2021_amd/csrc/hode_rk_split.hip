@@ -28,6 +28,7 @@
 //     are issued up front and pinned with sched_barrier; per-step stores are unpredicated (lanes beyond the batch hold
 //     bit-identical copies of patient B-1); the backward epilogue reduces with DPP row rotations + one LDS join.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/hode.h"
 #include "hode_common.hpp"
@@ -48,6 +49,7 @@ struct SplitArgs {
   const float* __restrict__ b1;
   float* __restrict__ h;
   float* __restrict__ tape;  // TAPE: [T-1][NS-1][B][4] expert stage states 1..NS-1 of every step (stage 0 is h itself)
+  float* __restrict__ ltape; // TAPE, rk4: [T-1][B][4 quad lanes][kLearnedTapeStages * MR] learned stage derivatives (see below)
   int* __restrict__ status;
   int B, T, K, perturb;
 };
@@ -127,6 +129,17 @@ template <> struct OwnSel<2> { typedef f2 type; };
 
 template <bool C, class A, class B> struct TypeSel { typedef A type; };
 template <class A, class B> struct TypeSel<false, A, B> { typedef B type; };
+
+// Learned-block tape (HODE_FLAG_TAPE, rk4): the forward also leaves tanh(W Y_s + b) of the LAST kLearnedTapeStages stages of
+// every step, in the lane order both kernels use ((patient, quad lane) -> kLearnedTapeStages * MR floats, contiguous per
+// wave).  The backward's learned waves load them TWO iterations ahead instead of recomputing D packed fmas + a tanh pair
+// per stage; the values are bit-identical to the recomputed ones.  Worth it only once the learned waves bound the
+// adjoint, i.e. with the theta wave (see split_bwd_body); measured per stage count in DESIGN.md 4.3c.
+#ifndef HODE_LTAPE_STAGES
+#define HODE_LTAPE_STAGES 2
+#endif
+constexpr int kLearnedTapeStages = HODE_LTAPE_STAGES;
+template <int METHOD> constexpr int sp_ltape_stages() { return METHOD == HODE_METHOD_RK4_38 ? kLearnedTapeStages : 0; }
 
 // The learned block as one lane of a patient's DPP quad sees it: MR = (D-4)/4 rows of tanh(W y + b).  The weights are kept
 // pre-multiplied by 2 log2(e), so tanh(z) = 1 - 2 / (exp2(z') + 1) needs no scaling instruction.
@@ -229,6 +242,47 @@ struct MlRows {
     if constexpr (MR == 2) *reinterpret_cast<float2*>(dst + 4 + 2 * q) = make_float2(v.x, v.y);
     else dst[4 + q] = v;
   }
+  // NL stage derivatives of this lane as one contiguous record of NL * MR floats (dst / src point at the lane's record)
+  template <int NL>
+  static HODE_DEV void store_tape(float* __restrict__ dst, const Own* __restrict__ k) {
+    if constexpr (MR == 2 && NL % 2 == 0) {
+#pragma unroll
+      for (int i = 0; i < NL; i += 2)
+        *reinterpret_cast<float4*>(dst + 4 * (i / 2)) = make_float4(k[i].x, k[i].y, k[i + 1].x, k[i + 1].y);
+    } else if constexpr (MR == 1 && NL == 4) {
+      *reinterpret_cast<float4*>(dst) = make_float4(k[0], k[1], k[2], k[3]);
+    } else if constexpr (MR == 1 && NL == 2) {
+      *reinterpret_cast<float2*>(dst) = make_float2(k[0], k[1]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if constexpr (MR == 2) *reinterpret_cast<float2*>(dst + 2 * i) = make_float2(k[i].x, k[i].y);
+        else dst[i] = k[i];
+      }
+    }
+  }
+  template <int NL>
+  static HODE_DEV void load_tape(const float* __restrict__ src, Own* __restrict__ k) {
+    if constexpr (MR == 2 && NL % 2 == 0) {
+#pragma unroll
+      for (int i = 0; i < NL; i += 2) {
+        const float4 v = *reinterpret_cast<const float4*>(src + 4 * (i / 2));
+        k[i] = pair2(v.x, v.y); k[i + 1] = pair2(v.z, v.w);
+      }
+    } else if constexpr (MR == 1 && NL == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+    } else if constexpr (MR == 1 && NL == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(src);
+      k[0] = v.x; k[1] = v.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if constexpr (MR == 2) { const float2 v = *reinterpret_cast<const float2*>(src + 2 * i); k[i] = pair2(v.x, v.y); }
+        else k[i] = src[i];
+      }
+    }
+  }
 };
 
 template <int D, int METHOD, bool ABLATE, bool HILL2, bool K1, bool TAPE>
@@ -328,6 +382,9 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
     if (a.T >= 3) dose_step(1, a.t[1], a.t[2]);
     Own yo = Ml::load_own(a.y0 + (size_t)p * D, q);
     if (live) Ml::store_own(a.h + (size_t)p * D, q, yo);
+    constexpr int NLT = sp_ltape_stages<METHOD>();
+    const size_t lt_step = (size_t)a.B * 4 * NLT * Ml::MR;           // floats per step of the learned tape
+    const unsigned lt_lane = ((unsigned)p * 4 + q) * NLT * Ml::MR;   // this lane's record
     __syncthreads();  // doses of steps 0 and 1 are in place
     __syncthreads();  // iteration 0: the expert wave fills ring[0]
     auto m_iter = [&](int it, auto PAR) {
@@ -353,6 +410,7 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       // no `if (live)`: a quad beyond the batch integrates a bit-identical copy of patient B-1 (p is clamped) and
       // stores the same values to the same address -- cheaper than an exec-mask branch every step
       Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
+      if constexpr (TAPE && NLT > 0) Ml::template store_tape<NLT>(a.ltape + (size_t)n * lt_step + lt_lane, k + (NS - NLT));
       __syncthreads();
     };
     for (int it = 1; it < a.T; it += 2) {
@@ -389,7 +447,9 @@ struct SplitBwdArgs {
   float* __restrict__ part_ml;   // [3 * nblk][M*D + M]
   float* __restrict__ part_th;   // [nblk][kNTheta]
   const float* __restrict__ tape;  // TAPE: what the forward kernel left (see SplitArgs)
+  const float* __restrict__ ltape;
   int B, T, K, perturb;
+  unsigned long long* dbg;  // HODE_SPLIT_STAMPS builds only: [5 waves][T] s_memtime at each wave's arrival at the step barrier (block 0)
 };
 
 // The cotangent algebra of one step of the scheme, shared by the expert wave (V = f2, two pairs) and the learned waves
@@ -446,10 +506,13 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][8];
   // THW: the 13 (15) theta-gradient accumulations of every stage run on a FIFTH wave, one iteration behind the expert wave
   // and off its cotangent chain (they are 40 % of its instructions, two v_log per stage among them): the expert wave hands
-  // over the stage cotangents g_s through gring, the theta wave reads the stage states from the forward's tape and forms
-  // the doses itself.  Only with the tape (without it the stage states exist nowhere but in the expert wave).
+  // over the stage cotangents g_s through gring, the theta wave reads the stage states from the forward's tape and gets
+  // the doses forwarded (tdring).  Only with the tape (without it the stage states exist nowhere but in the expert wave).
   constexpr bool THW = TAPE && NEED_TH;
   __shared__ __attribute__((aligned(16))) float gring[2][4][kSplitPatients + 1][4];   // row kSplitPatients: zeros
+  // the doses of the step the expert wave has just adjoined (Dose(t_s) [0..3], dDose/dkel [4..7]), forwarded to the theta
+  // wave: dring itself is refilled by the learned waves while the theta wave would read it
+  __shared__ __attribute__((aligned(16))) float tdring[2][kSplitPatients][8];
   // epilogue: the 4 per-row (16-lane) partial sums of every gradient entry of a wave, summed across rows from here
   __shared__ float red[4][4][M * D + M];
   extern __shared__ float tg[];  // time grid, see sp_stage_grid
@@ -460,6 +523,11 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   const size_t row = (size_t)a.B * D;
   const int T = a.T;
   sp_stage_grid(tg, a.t, a.T);  // visible after the __syncthreads that precedes both pipelines' loops
+#ifdef HODE_SPLIT_STAMPS
+#define HODE_SSTAMP(k) if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[(size_t)wave * a.T + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define HODE_SSTAMP(k)
+#endif
 
   if (wave == 0) {
     // ================================================================== expert wave
@@ -558,6 +626,10 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
           const float4 d1 = *reinterpret_cast<const float4*>(&dring[par][slot][4]);
           dv[0].v = d0.x; dv[1].v = d0.y; dv[2].v = d0.z; dv[3].v = d0.w;
           dv[0].dk = d1.x; dv[1].dk = d1.y; dv[2].dk = d1.z; dv[3].dk = d1.w;
+          if constexpr (THW) {
+            *reinterpret_cast<float4*>(&tdring[par ^ 1][slot][0]) = d0;
+            *reinterpret_cast<float4*>(&tdring[par ^ 1][slot][4]) = d1;
+          }
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -586,6 +658,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       }
       // ---- (a) stage states of step T-3-k for the learned waves' next iteration
       if (T - 3 - k >= 0) publish(T - 3 - k, par);
+      HODE_SSTAMP(k)
       __syncthreads();
     };
     for (int k = 0; k < T; k += 2) {
@@ -610,11 +683,6 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     const bool mine = lane < kSplitPatients;
     const int p = min(b0 + slot, a.B - 1);
     const int gslot = mine ? lane : kSplitPatients;   // spare lanes read the zero row: their contributions are exactly zero
-    DoseSched<K1> ds;
-    ds.dosage = a.dosage[p];
-    ds.K = a.K;
-    ds.taus = a.dose_times + (size_t)p * a.K;
-    ds.tau0 = K1 ? ds.taus[0] : 0.f;
     const float ln_ec50 = log_f32(th.ec50);
     if (lane < 32) (&gring[lane >> 4][(lane >> 2) & 3][kSplitPatients][0])[lane & 3] = 0.f;
     const unsigned lane_h = (unsigned)p * D, lane_t = (unsigned)p * 4;
@@ -634,13 +702,16 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     };
     // the theta terms of step m; stages in the order the expert wave's adjoint visits them (3, 2, 1, 0), so that every
     // accumulator sees its terms in the same order as when the expert wave accumulates them itself
-    auto theta_step = [&](int m, int gpar) {
-      const float t0 = tg[m], t1 = tg[m + 1];
+    auto theta_step = [&](int gpar) {
+      const float4 d0 = *reinterpret_cast<const float4*>(&tdring[gpar][slot][0]);
+      const float4 d1 = *reinterpret_cast<const float4*>(&tdring[gpar][slot][4]);
+      const float dvv[4] = {d0.x, d0.y, d0.z, d0.w}, dvk[4] = {d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
       for (int si = 0; si < NS; ++si) {
         const int s = NS - 1 - si;
         const float4 gv = *reinterpret_cast<const float4*>(&gring[gpar][s][gslot][0]);
-        const DoseVal dv = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, METHOD == HODE_METHOD_MIDPOINT && s == 1 ? 1 : (METHOD == HODE_METHOD_RK4_38 ? s : 0)), th.kel);
+        DoseVal dv;
+        dv.v = dvv[s]; dv.dk = dvk[s];
         const float g[4] = {gv.x, gv.y, gv.z, gv.w};
         roche_theta_grad<ABLATE, HILL2>(th, ln_ec50, dv, tp[s], g, dth);
       }
@@ -648,15 +719,16 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     __syncthreads();  // the expert wave's prologue
     auto t_iter = [&](int k, auto PAR) {
       constexpr int gpar = decltype(PAR)::value;  // == (k - 1) & 1: what the expert wave wrote in iteration k - 1
-      if (k >= 2) theta_step(T - k, gpar);
+      if (k >= 2) theta_step(gpar);
       if (k >= 1 && T - k - 1 >= 0) fetch(T - k - 1);
+      HODE_SSTAMP(k)
       __syncthreads();
     };
     for (int k = 0; k < T; k += 2) {
       t_iter(k, IC<1>{});
       if (k + 1 < T) t_iter(k + 1, IC<0>{});
     }
-    if (T >= 2) theta_step(0, (T - 1) & 1);
+    if (T >= 2) theta_step((T - 1) & 1);
 #pragma unroll
     for (int i = 0; i < kNTheta; ++i) {
       const float v = row_sum(dth[i]);
@@ -705,10 +777,19 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     // the operands of iteration k+1 are fetched during iteration k (the state is needed by the very first instruction of
     // an iteration: an un-hidden HBM round trip would cost a quarter of it)
     Own yo_nx, gh_nx;
+    constexpr int NLT = TAPE ? sp_ltape_stages<METHOD>() : 0;
+    const size_t lt_step = (size_t)a.B * 4 * NLT * MR;
+    const unsigned lt_lane = ((unsigned)p * 4 + q) * NLT * MR;
+    Own lt_nx[NLT > 0 ? NLT : 1], lt_n2[NLT > 0 ? NLT : 1];   // the tape records of the next two iterations
     {
       const int m0 = T >= 2 ? T - 2 : 0;
+      const int m1 = m0 >= 1 ? m0 - 1 : 0;
       yo_nx = Ml::load_own(a.h + (size_t)m0 * row + (size_t)p * D, q);
       gh_nx = Ml::load_own(a.grad_h + (size_t)m0 * row + (size_t)p * D, q);
+      if constexpr (NLT > 0) {
+        Ml::template load_tape<NLT>(a.ltape + (size_t)m0 * lt_step + lt_lane, lt_nx);
+        Ml::template load_tape<NLT>(a.ltape + (size_t)m1 * lt_step + lt_lane, lt_n2);
+      }
     }
     __syncthreads();  // the expert wave's prologue fills ring 0
     auto m_iter = [&](int k, auto PAR) {
@@ -718,10 +799,16 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         const float t0 = tg[m], t1 = tg[m + 1];
         const float dt = t1 - t0;
         const Own yo = yo_nx, gh = gh_nx;
+        Own lt[NLT > 0 ? NLT : 1];
+#pragma unroll
+        for (int i = 0; i < NLT; ++i) { lt[i] = lt_nx[i]; lt_nx[i] = lt_n2[i]; }
         {
-          const int mn = m >= 1 ? m - 1 : 0;  // clamped: the last prefetch is simply unused
+          const int mn = m >= 1 ? m - 1 : 0;  // clamped: the last prefetches are simply unused
           yo_nx = Ml::load_own(a.h + (size_t)mn * row + (size_t)p * D, q);
           gh_nx = Ml::load_own(a.grad_h + (size_t)mn * row + (size_t)p * D, q);
+          // the tape record TWO iterations ahead: one iteration (~0.7 us) does not cover its HBM round trip (with one the
+          // tape bought nothing: 89.7 us with and without it; with two 80.2).  h / grad_h stay at one: two measured 1 % slower
+          if constexpr (NLT > 0) Ml::template load_tape<NLT>(a.ltape + (size_t)(m >= 2 ? m - 2 : 0) * lt_step + lt_lane, lt_n2);
         }
         // ---- recompute the learned stage derivatives
         typename Ml::Stage Y[4];
@@ -741,7 +828,8 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         for (int s = 0; s < NS; ++s) {
           const Own Yo = sp_stage_state<METHOD>(s, yo, dt, so[0], so[1], so[2]);
           Y[s] = Ml::stage(e[s], Yo);
-          so[s] = ml.rhs(Y[s]);
+          if (s >= NS - NLT) so[s] = lt[s - (NS - NLT) < 0 ? 0 : s - (NS - NLT)];  // what the forward computed, bit for bit
+          else so[s] = ml.rhs(Y[s]);
         }
         // ---- adjoint of the stages
         sp_adjoint_step<METHOD>(lam, dt, [&](int s, Own gs) {
@@ -775,6 +863,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         });
         lam = vfma(lv, gh, lam);
       }
+      HODE_SSTAMP(k)
       __syncthreads();
     };
     for (int k = 0; k < T; k += 2) {
@@ -917,13 +1006,21 @@ static size_t split_partials_bytes(const hode_solve_desc* d) {
   const size_t M = d->latent_dim - 4;
   return al256s(nblk * 3 * (M * d->latent_dim + M) * sizeof(float)) + al256s(nblk * kNTheta * sizeof(float));
 }
-static size_t split_tape_bytes(const hode_solve_desc* d) {
+static size_t split_etape_bytes(const hode_solve_desc* d) {   // expert stage states
   if (!(d->flags & HODE_FLAG_TAPE) || d->n_times < 2) return 0;
-  return (size_t)(d->n_times - 1) * (n_stages(d->method) - 1) * d->batch * 4 * sizeof(float);
+  return al256s((size_t)(d->n_times - 1) * (n_stages(d->method) - 1) * d->batch * 4 * sizeof(float));
 }
+static size_t split_ltape_bytes(const hode_solve_desc* d) {   // learned stage derivatives (rk4 only)
+  if (!(d->flags & HODE_FLAG_TAPE) || d->n_times < 2 || n_stages(d->method) != 4 || kLearnedTapeStages == 0) return 0;
+  return al256s((size_t)(d->n_times - 1) * d->batch * (d->latent_dim - 4) * kLearnedTapeStages * sizeof(float));
+}
+static size_t split_tape_bytes(const hode_solve_desc* d) { return split_etape_bytes(d) + split_ltape_bytes(d); }
 size_t split_workspace_bytes(const hode_solve_desc* d) { return split_partials_bytes(d) + split_tape_bytes(d); }
 static float* split_tape(const hode_solve_desc* d) {
-  return split_tape_bytes(d) ? (float*)((char*)d->workspace + split_partials_bytes(d)) : nullptr;
+  return split_etape_bytes(d) ? (float*)((char*)d->workspace + split_partials_bytes(d)) : nullptr;
+}
+static float* split_ltape(const hode_solve_desc* d) {
+  return split_ltape_bytes(d) ? (float*)((char*)d->workspace + split_partials_bytes(d) + split_etape_bytes(d)) : nullptr;
 }
 
 int split_rk_bwd(const hode_solve_desc* d, hipStream_t s) {
@@ -938,6 +1035,10 @@ int split_rk_bwd(const hode_solve_desc* d, hipStream_t s) {
   a.part_th = (float*)(ws + al256s((size_t)nblk * 3 * Pml * sizeof(float)));
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
   a.tape = split_tape(d);
+  a.ltape = split_ltape(d);
+#ifdef HODE_SPLIT_STAMPS
+  if (const char* env = getenv("HODE_SPLIT_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(env, nullptr, 0);
+#endif
   const bool abl = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
   int e;
   if (d->latent_dim == 8) e = abl ? split_bwd_method<8, true>(d, a, s) : split_bwd_method<8, false>(d, a, s);
@@ -956,6 +1057,7 @@ int split_rk_fwd(const hode_solve_desc* d, hipStream_t s) {
   a.h = d->h; a.status = d->status;
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
   a.tape = split_tape(d);
+  a.ltape = split_ltape(d);
   const bool abl = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
   if (d->latent_dim == 8) return abl ? split_method<8, true>(d, a, s) : split_method<8, false>(d, a, s);
   return abl ? split_method<12, true>(d, a, s) : split_method<12, false>(d, a, s);

@@ -1,0 +1,25 @@
+"""Which wave of a split-adjoint workgroup arrives last at the step barrier (s_memtime stamps, block 0).
+Needs: HODE_SPLIT_FLAGS="-fno-slp-vectorize -DHODE_SPLIT_STAMPS" python build_hip.py   (product builds carry no stamps)"""
+import os, sys, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
+import bench
+dev = torch.device("cuda:0")
+T = bench.T
+dbg = torch.zeros(5 * T, dtype=torch.int64, device=dev)
+os.environ["HODE_SPLIT_DBG_PTR"] = hex(dbg.data_ptr())
+prob = bench.solver_problem(0)
+plan = bench.build_plan(dev, prob, lanes=0, need_theta=True, tape=True)
+for _ in range(3):
+    plan.step()
+torch.cuda.synchronize()
+s = dbg.cpu().numpy().reshape(5, T).astype(np.int64)
+names = ["expert", "learned 1", "learned 2", "learned 3", "theta"]
+ks = np.arange(10, T - 10)
+arr = s[:, ks]                      # arrival of each wave at the barrier of iteration k
+last = arr.max(axis=0)
+period = np.diff(last)
+print("step period (last arrival to last arrival): median %d cycles = %.0f ns" % (np.median(period), np.median(period) / 2.4))
+for w in range(5):
+    slack = last - arr[w]
+    print("%-10s arrives %5d cycles (median) before the last wave; last in %2d %% of the steps" % (names[w], np.median(slack), 100 * np.mean(arr[w] == last)))
