@@ -525,6 +525,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   sp_stage_grid(tg, a.t, a.T);  // visible after the __syncthreads that precedes both pipelines' loops
 #ifdef HODE_SPLIT_STAMPS
 #define HODE_SSTAMP(k) if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[(size_t)wave * a.T + (k)] = __builtin_amdgcn_s_memtime();
+  if (a.dbg && blockIdx.x < 8 && lane == 0) a.dbg[(size_t)5 * a.T + blockIdx.x * 8 + wave] = __builtin_amdgcn_s_getreg(63492);  // HW_ID: SIMD in bits 5:4
 #else
 #define HODE_SSTAMP(k)
 #endif

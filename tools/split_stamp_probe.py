@@ -6,14 +6,17 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neur
 import bench
 dev = torch.device("cuda:0")
 T = bench.T
-dbg = torch.zeros(5 * T, dtype=torch.int64, device=dev)
+dbg = torch.zeros(5 * T + 64, dtype=torch.int64, device=dev)
 os.environ["HODE_SPLIT_DBG_PTR"] = hex(dbg.data_ptr())
 prob = bench.solver_problem(0)
 plan = bench.build_plan(dev, prob, lanes=0, need_theta=True, tape=True)
 for _ in range(3):
     plan.step()
 torch.cuda.synchronize()
-s = dbg.cpu().numpy().reshape(5, T).astype(np.int64)
+raw = dbg.cpu().numpy().astype(np.int64)
+s = raw[:5 * T].reshape(5, T)
+hw = raw[5 * T:].reshape(8, 8)[:, :5]
+print('SIMD of waves 0..4 (expert, learned x3, helper) in workgroups 0..7:', [[int((v >> 4) & 3) for v in row] for row in hw])
 names = ["expert", "learned 1", "learned 2", "learned 3", "theta"]
 ks = np.arange(10, T - 10)
 arr = s[:, ks]                      # arrival of each wave at the barrier of iteration k
