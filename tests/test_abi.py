@@ -86,7 +86,8 @@ def test_workspace_query(lib):
     # HODE_FLAG_TAPE: forward and backward share one buffer = partials + 16 B per patient, interval and inner stage
     d.flags, d.method = L.FLAG_TAPE, L.METHODS["rk4"]
     nt = lib.hode_workspace_bytes(d, L.WS_RK_BWD)
-    assert nt == n + 99 * 3 * 10000 * 16 and lib.hode_workspace_bytes(d, L.WS_RK_FWD) == nt
+    # expert stage states (3 x 16 B) + the learned block's last two stage derivatives (2 x 8 floats) per patient and interval
+    assert nt == n + 99 * 3 * 10000 * 16 + 99 * 10000 * 8 * 2 * 4 and lib.hode_workspace_bytes(d, L.WS_RK_FWD) == nt
     d.method = L.METHODS["midpoint"]
     assert lib.hode_workspace_bytes(d, L.WS_RK_FWD) == n + 99 * 1 * 10000 * 16
     d.method = L.METHODS["euler"]  # single stage: nothing to tape
