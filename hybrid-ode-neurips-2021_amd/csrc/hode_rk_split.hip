@@ -49,6 +49,7 @@ struct SplitArgs {
   const float* __restrict__ b1;
   float* __restrict__ h;
   float* __restrict__ tape;  // TAPE: [T-1][NS-1][B][4] expert stage states 1..NS-1 of every step (stage 0 is h itself)
+  unsigned long long* dbg;   // HODE_SPLIT_STAMPS builds only: [4 waves][T] s_memtime at each wave's arrival at the step barrier (block 0)
   float* __restrict__ ltape; // TAPE, rk4: [T-1][B][4 quad lanes][kLearnedTapeStages * MR] learned stage derivatives (see below)
   int* __restrict__ status;
   int B, T, K, perturb;
@@ -302,6 +303,11 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
   const RocheTheta th = load_theta(a.theta, ABLATE);
   const size_t row = (size_t)a.B * D;
   sp_stage_grid(tg, a.t, a.T);  // visible after the first __syncthreads of either pipeline
+#ifdef HODE_SPLIT_STAMPS
+#define HODE_FSTAMP(k) if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[(size_t)wave * a.T + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define HODE_FSTAMP(k)
+#endif
 
   if (wave == 0) {
     // ------------------------------------------------------------------ expert pipeline: one patient per lane
@@ -351,6 +357,7 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
         // unpredicated (see the learned waves' store): spare lanes hold bit-identical copies of a live patient
         *reinterpret_cast<float4*>(a.h + (size_t)(it + 1) * row + lane_h) = make_float4(ya.x, ya.y, yb.x, yb.y);
       }
+      HODE_FSTAMP(it)
       __syncthreads();
     };
     for (int it = 0; it < a.T; it += 2) {
@@ -411,6 +418,7 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       // stores the same values to the same address -- cheaper than an exec-mask branch every step
       Ml::store_own(a.h + (size_t)(n + 1) * row + (size_t)p * D, q, yo);
       if constexpr (TAPE && NLT > 0) Ml::template store_tape<NLT>(a.ltape + (size_t)n * lt_step + lt_lane, k + (NS - NLT));
+      HODE_FSTAMP(it)
       __syncthreads();
     };
     for (int it = 1; it < a.T; it += 2) {
@@ -1059,6 +1067,9 @@ int split_rk_fwd(const hode_solve_desc* d, hipStream_t s) {
   a.B = d->batch; a.T = d->n_times; a.K = d->n_dose; a.perturb = d->perturb;
   a.tape = split_tape(d);
   a.ltape = split_ltape(d);
+#ifdef HODE_SPLIT_STAMPS
+  if (const char* env = getenv("HODE_SPLIT_FWD_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(env, nullptr, 0);
+#endif
   const bool abl = d->rhs_kind == HODE_RHS_ROCHE_ABLATE;
   if (d->latent_dim == 8) return abl ? split_method<8, true>(d, a, s) : split_method<8, false>(d, a, s);
   return abl ? split_method<12, true>(d, a, s) : split_method<12, false>(d, a, s);

@@ -8,6 +8,8 @@ dev = torch.device("cuda:0")
 T = bench.T
 dbg = torch.zeros(5 * T + 64, dtype=torch.int64, device=dev)
 os.environ["HODE_SPLIT_DBG_PTR"] = hex(dbg.data_ptr())
+dbgf = torch.zeros(4 * T, dtype=torch.int64, device=dev)
+os.environ["HODE_SPLIT_FWD_DBG_PTR"] = hex(dbgf.data_ptr())
 prob = bench.solver_problem(0)
 plan = bench.build_plan(dev, prob, lanes=0, need_theta=True, tape=True)
 for _ in range(3):
@@ -26,3 +28,11 @@ print("step period (last arrival to last arrival): median %d cycles = %.0f ns" %
 for w in range(5):
     slack = last - arr[w]
     print("%-10s arrives %5d cycles (median) before the last wave; last in %2d %% of the steps" % (names[w], np.median(slack), 100 * np.mean(arr[w] == last)))
+print("forward kernel:")
+sf = dbgf.cpu().numpy().astype(np.int64).reshape(4, T)
+ks = np.arange(10, T - 10)
+arr = sf[:, ks]
+last = arr.max(axis=0)
+print("step period: median %d cycles = %.0f ns" % (np.median(np.diff(last)), np.median(np.diff(last)) / 2.4))
+for w in range(4):
+    print("%-10s arrives %5d cycles (median) before the last wave; last in %2d %% of the steps" % (names[w], np.median(last - arr[w]), 100 * np.mean(arr[w] == last)))
