@@ -6,6 +6,8 @@ the ``cat([x, a]) * cat([mask, 1])`` that feeds them.
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -58,10 +60,17 @@ def _splitk_tn(lhs, rhs):
             break
     if P == 1:
         return lhs.t() @ rhs
-    part = torch.bmm(lhs.view(P, K // P, -1).transpose(1, 2), rhs.view(P, K // P, -1))
+    # The product is formed as (rhs^T lhs)^T: with M = 4H = 640 and N = 244 the library's 256 x 128 macro tile wastes 20 % on
+    # the 640 x 244 result (3 x 2 tiles) and 5 % on 244 x 640 (1 x 5): 2.7 -> 2.3 ms at K = 1e6 in isolation
+    # (tools/gemm_orient_probe.py), 0.05 ms inside the training step (same-call A/B, HODE_LSTM_GEMM_MN=1)
+    if os.environ.get("HODE_LSTM_GEMM_MN"):   # A/B switch: the product in its natural orientation
+        part = torch.bmm(lhs.view(P, K // P, -1).transpose(1, 2), rhs.view(P, K // P, -1))
+        ones = torch.ones((1, P), device=part.device, dtype=part.dtype)
+        return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2])
+    part = torch.bmm(rhs.view(P, K // P, -1).transpose(1, 2), lhs.view(P, K // P, -1))
     # fold the P partial products with a (1 x P) GEMM: torch's strided sum(0) over this shape reads at ~0.3 TB/s
     ones = torch.ones((1, P), device=part.device, dtype=part.dtype)
-    return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2])
+    return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2]).t()
 
 
 class _LstmEncode(torch.autograd.Function):
