@@ -23,6 +23,10 @@
 //     third LDS ring (4 stages in parallel instead of 4 x 9 serial instructions);
 //   * HODE_FLAG_TAPE: the forward leaves the expert block's intermediate stage states in the workspace, the backward's
 //     expert wave loads them an iteration ahead instead of re-integrating (bit-identical, +16 B x 3 per patient / step);
+//     for rk4 also tanh(W Y_s + b) of the last two stages (loaded two iterations ahead by the backward's learned waves);
+//   * adjoint with the tape and theta gradients: a FIFTH wave accumulates the 13 (15) expert-parameter gradients one
+//     iteration behind the expert wave, off its cotangent chain (stage cotangents and doses through two LDS rings, stage
+//     states from the tape); it shares a SIMD with the expert wave (100 -> 80 us together with the tape);
 //   * the time grid sits in LDS (dynamic shared memory, hence n_times <= 8192 for this layout);
 //   * time loops unrolled by two through a generic lambda so that ring parities are immediates; all ring reads of a step
 //     are issued up front and pinned with sched_barrier; per-step stores are unpredicated (lanes beyond the batch hold
