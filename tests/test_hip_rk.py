@@ -310,14 +310,17 @@ def test_plan_overwrite_flag_matches_accumulating_backward(lanes):
 @pytest.mark.gpu
 @pytest.mark.parametrize("D", [8, 12])
 @pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
-def test_split_tape_matches_recompute(D, method):
-    """HODE_FLAG_TAPE: the forward leaves the expert stage states in the workspace, the backward reads them instead of
-    re-integrating -- the same numbers, so every output must be bit-identical to the tape-less backward."""
+@pytest.mark.parametrize("N,T", [(101, 9), (1, 2), (47, 3), (49, 4), (96, 5)])
+def test_split_tape_matches_recompute(D, method, N, T):
+    """HODE_FLAG_TAPE: the forward leaves the expert stage states (rk4: and the learned block's last two stage derivatives)
+    in the workspace, the backward reads them instead of re-integrating and runs the theta gradients on a fifth wave -- the
+    same numbers in the same order, so every output must be bit-identical to the tape-less 4-wave backward.  Short grids
+    exercise the pipelines' prologues / epilogues (the theta wave lags two iterations, the learned tape is fetched two
+    ahead), batch sizes around the 48-patient workgroup the spare lanes."""
     dev = _dev()
     from hode.plan import RocheRKPlan
     from hode.solver import pack_theta
     from oracle.rhs import THETA_NAMES
-    N, T = 101, 9
     inp, f = _case(N, T, D, seed=7 + D)
     cot = torch.randn(T, N, D, generator=torch.Generator().manual_seed(6)).to(dev)
     theta = pack_theta([getattr(f, n).detach().to(dev) for n in THETA_NAMES], dev)
