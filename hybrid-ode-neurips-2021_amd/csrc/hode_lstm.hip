@@ -40,6 +40,17 @@ struct LstmArgs {
   unsigned long long* dbg;  // HODE_LSTM_STAMPS builds only: [T][8] s_memtime stamps of wave 0 of block 0
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release over ALL address
+// spaces, i.e. s_waitcnt vmcnt(0): every wave would sit out the HBM write burst of the step (tape stores in the forward,
+// dG / h_prev rows in the BPTT -- 32 MB per step over the chip, written by all workgroups at the same moment) before the
+// matrix pipe starts again.  Nothing in these kernels reads back what they store, so the stores may drain under the next
+// step's MFMAs.
+HODE_DEV void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 HODE_DEV float sigmoid_gate(float x) {
   // 1 / (1 + exp(-x)) on v_exp + v_rcp (<= 2 ulp); exp overflow -> rcp(inf) = 0, underflow -> 1
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
     HODE_FSTAMP(2)
     if (more) stage_x(nxt, t_next);
     HODE_FSTAMP(3)
-    __syncthreads();
+    lds_barrier();
     HODE_FSTAMP(4)
   }
 #undef HODE_FSTAMP
@@ -407,10 +418,15 @@ __global__ void lstm_pack_hh_kernel(const float* __restrict__ w_hh, float* __res
   }
 }
 
+#ifndef HODE_BPTT_BODY_HOOK
+#define HODE_BPTT_BODY_HOOK 1
+#endif
 #ifndef HODE_BPTT_BURST
 #define HODE_BPTT_BURST 1   // 1: element-wise burst, then the MFMAs with only loads between them; 0: 1 MFMA : 1-2 VALU interleave (3 % slower, tools/micro/mfma_valu_overlap.hip)
 #endif
-template <int NT, int TPW>
+// FLAT: H == 16 TPW (no padded hidden units): the store phase copies whole dG rows (see there); a template parameter so
+// that only one of the two store loops -- and its hoisted addresses -- exists in an instantiation
+template <int NT, int TPW, bool FLAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_kernel(LstmBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BT = 16 * NT;
@@ -572,7 +588,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // weights of row block R + 2 at the start of row block R; the group barriers below pin that issue order (left to
     // itself the scheduler sinks every load next to its use, and an in-order vmcnt wait on the newest load waits for all).
     auto body = [&](int tt) {
-#ifdef HODE_LSTM_STAMPS
+#if defined(HODE_LSTM_STAMPS) || HODE_BPTT_BODY_HOOK
+      // In product builds p.dbg is null and this is a never-taken branch -- KEPT ON PURPOSE: it ends the basic block at every
+      // unit tile.  Without it the ten bodies of a step are one block and the kernel is 0.47 ms (15 %) slower at the bench
+      // shape (same-call A/B of the two builds, tools/lstm_time_probe.py): the scheduler's / waitcnt pass's choices over a
+      // 3 000-instruction block undo part of the issue order pinned below.
       if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[(size_t)(p.T + s) * 16 + tt] = __builtin_amdgcn_s_memtime();  // no wait
 #endif
       TapeOps& o_nx = ops[tt & 1];
@@ -630,7 +650,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int j = 0; j < MG; ++j) { wfr[0][j] = n0[j]; wfr[1][j] = n1[j]; }
     }
     HODE_LSTAMP(1)
-    __syncthreads();
+    lds_barrier();
     HODE_LSTAMP(2)
     // coalesced row-major stores of this step's dG and h_prev tiles.  Wave w stores patients w, w+4, ...; the loops run
     // over (patient, gate, unit) explicitly -- a flat index would need two integer divisions per element, which made
@@ -645,6 +665,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // wave and step, 8.6 us of a 36.6 us step (tools/lstm_stamp_probe.py) -- not bandwidth bound.
       const bool vec = (H & 3) == 0;
       const bool lane_g = 4 * l < H;           // H <= 160: one 16-byte chunk per lane and gate row covers a row
+      if constexpr (FLAT) {
+        // H a multiple of 16 (every shipped encoder): a patient's dG row is 4H contiguous floats in LDS and in HBM -- a flat
+        // copy in 16-byte chunks over ALL 64 lanes (ceil(H/64) instructions instead of 4 with 4H/16 <= 40 lanes busy), software
+        // pipelined: the LDS reads of the wave's next patient are in flight while this patient's stores issue
+        constexpr int NC = (Hp + 63) / 64;       // 16-byte chunks of the dG row per lane
+        constexpr int NHC = (Hp + 63) / 64;      // floats of the h_prev row per lane
+        struct Row { f32x4 v[NC]; float h[NHC]; };
+        auto ld = [&](int b, Row& r) {
+          const float* drow = dgt + (size_t)b * LDG;
+          const float* hrow = hT + (size_t)b * LDH;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int f = l + 64 * c;
+            r.v[c] = f < Hp ? *reinterpret_cast<const f32x4*>(drow + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int k = 0; k < NHC; ++k) r.h[k] = (l + 64 * k < H) ? hrow[l + 64 * k] : 0.f;
+        };
+        auto st = [&](int b, const Row& r) {
+          float* grow = gdst + (size_t)b * 4 * H;
+          float* hd = hdst + (size_t)b * W + I;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int f = l + 64 * c;
+            if (f < Hp) *reinterpret_cast<f32x4*>(grow + 4 * f) = r.v[c];
+          }
+#pragma unroll
+          for (int k = 0; k < NHC; ++k)
+            if (l + 64 * k < H) hd[l + 64 * k] = r.h[k];
+        };
+        Row ra, rb;
+        int b = w;
+        if (b < nvalid) ld(b, ra);
+        for (; b < nvalid; b += 8) {
+          if (b + 4 < nvalid) ld(b + 4, rb);
+          __builtin_amdgcn_sched_barrier(0);   // the next patient's reads stay ahead of this patient's stores
+          st(b, ra);
+          if (b + 4 < nvalid) {
+            if (b + 8 < nvalid) ld(b + 8, ra);
+            __builtin_amdgcn_sched_barrier(0);
+            st(b + 4, rb);
+          }
+        }
+      } else
       for (int b = w; b < nvalid; b += 8) {
         const int b2 = b + 4;
         const bool two = b2 < nvalid;
@@ -689,7 +753,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     HODE_LSTAMP(3)
-    __syncthreads();
+    lds_barrier();
     HODE_LSTAMP(4)
     // exchange the K-split partial products: slab[w][u'][patient]
 #pragma unroll
@@ -700,7 +764,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int rr = 0; rr < 4; ++rr)
           slab_w[(16 * mt + rr) * LD + 16 * c] = acc[mt][c][rr];
     HODE_LSTAMP(5)
-    __syncthreads();
+    lds_barrier();
     HODE_LSTAMP(6)
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
@@ -711,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     HODE_LSTAMP(7)
-    __syncthreads();
+    lds_barrier();
   }
 #undef HODE_LSTAMP
 }
@@ -864,14 +928,19 @@ extern "C" int hode_lstm_fwd(const hode_lstm_desc* d, void* stream) {
 
 namespace {
 
-template <int NT, int TPW>
-int launch_bwd_one(const LstmGeom& G, const hode::LstmBwdArgs& a, hipStream_t s) {
-  if (int e = hode::hip_fail(hipFuncSetAttribute((const void*)hode::lstm_bwd_kernel<NT, TPW>,
+template <int NT, int TPW, bool FLAT>
+int launch_bwd_flat(const LstmGeom& G, const hode::LstmBwdArgs& a, hipStream_t s) {
+  if (int e = hode::hip_fail(hipFuncSetAttribute((const void*)hode::lstm_bwd_kernel<NT, TPW, FLAT>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G.lds_bwd_bytes),
                              "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
     return e;
-  hipLaunchKernelGGL((hode::lstm_bwd_kernel<NT, TPW>), dim3(G.nblk), dim3(256), G.lds_bwd_bytes, s, a);
+  hipLaunchKernelGGL((hode::lstm_bwd_kernel<NT, TPW, FLAT>), dim3(G.nblk), dim3(256), G.lds_bwd_bytes, s, a);
   return hode::hip_fail(hipGetLastError(), "lstm_bwd launch");
+}
+
+template <int NT, int TPW>
+int launch_bwd_one(const LstmGeom& G, const hode::LstmBwdArgs& a, hipStream_t s) {
+  return a.H == 16 * TPW ? launch_bwd_flat<NT, TPW, true>(G, a, s) : launch_bwd_flat<NT, TPW, false>(G, a, s);
 }
 
 template <int NT>
