@@ -528,6 +528,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define HODE_LSTAMP(i)
 #endif
+  const int nA0 = nvalid * p.AD;
+  const int act_b = p.AD > 0 ? tid / max(p.AD, 1) : 0, act_u = tid - act_b * p.AD;
+  float a_nx = 0.f;
+  if (p.a && nA0 <= 256 && tid < nA0) {
+    const int t0 = p.reverse ? 0 : p.T - 1;   // time index of the first backward step (s = T - 1)
+    a_nx = p.a[((size_t)t0 * p.B + b0) * p.AD + tid];
+  }
   for (int s = p.T - 1; s >= 0; --s) {
     const int t = p.reverse ? p.T - 1 - s : s;
     HODE_LSTAMP(0)
@@ -551,9 +558,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float* hdst = p.h_prev + ((size_t)t * p.B + b0) * W;
       const float* asrc = p.a ? p.a + ((size_t)t * p.B + b0) * p.AD : nullptr;
       const int nA = nvalid * p.AD, nP = nvalid * (W - I - H);
-      for (int e = tid; e < nA; e += 256) {
-        const int b = e / p.AD, u = e - b * p.AD;
-        hdst[(size_t)b * W + p.OBS + u] = asrc[e];
+      if (nA <= 256) {
+        // one action value per thread, loaded ONE STEP AHEAD (a_nx): a load consumed by the next store stalls its wave for an
+        // HBM round trip at the head of the step, and the whole workgroup waits for that wave at the end of the tile loop
+        if (tid < nA) hdst[(size_t)act_b * W + p.OBS + act_u] = a_nx;
+        if (s > 0 && tid < nA) {
+          const int t_n = p.reverse ? p.T - s : s - 1;   // time index of backward step s - 1
+          a_nx = p.a[((size_t)t_n * p.B + b0) * p.AD + tid];
+        }
+      } else {
+        for (int e = tid; e < nA; e += 256) {
+          const int b = e / p.AD, u = e - b * p.AD;
+          hdst[(size_t)b * W + p.OBS + u] = asrc[e];
+        }
       }
       for (int e = tid; e < nP; e += 256) {
         const int b = e / (W - I - H), u = e - b * (W - I - H);
