@@ -53,7 +53,8 @@ def _status_error(status):
 
 class _RocheDopri5(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y0, theta, w, b, t, dosage, dose_times, rtol, atol, ablate, lanes, max_steps, detach_first_step):
+    def forward(ctx, y0, theta, w, b, t, dosage, dose_times, rtol, atol, ablate, lanes, max_steps, detach_first_step,
+                grad_enabled=True):
         _require_gpu(y0, theta, t, dosage, dose_times)
         lib = L.lib()
         B, D = y0.shape
@@ -66,7 +67,9 @@ class _RocheDopri5(torch.autograd.Function):
         # Without a backward to follow (evaluate() integrates mc_itr * B latents under no_grad) the accepted-state tape
         # shrinks to two rows and the step bound costs 24 bytes per step; with one, the tape is (steps + 1) * B * D * 4
         # bytes and a run that outgrows it is repeated with a larger one -- as long as the device can hold it.
-        no_tape = not any(ctx.needs_input_grad[:4])
+        # `needs_input_grad` reflects the inputs' requires_grad, not the grad mode (Parameters under torch.no_grad() still
+        # say True), and inside forward() grad mode is always off: the wrapper samples it before .apply().
+        no_tape = not (grad_enabled and any(ctx.needs_input_grad[:4]))
         steps = int(max_steps) if max_steps else ((1 << 20) if no_tape else 16 * T + 64)
         while True:
             status = torch.zeros(1, device=y0.device, dtype=torch.int32)
@@ -96,7 +99,7 @@ class _RocheDopri5(torch.autograd.Function):
                 steps *= 4  # tape too small: retry with a larger one (refused above once it no longer fits the device)
                 continue
             break
-        last_stats.update(n_accepted=n_acc.value, n_rejected=n_rej.value)
+        last_stats.update(n_accepted=n_acc.value, n_rejected=n_rej.value, no_tape=no_tape, workspace_bytes=int(nbytes))
         if st:
             # torchdiffeq raises AssertionError here, which the reference's training loop does NOT catch; a RuntimeError
             # subclass lets `except RuntimeError` (training_utils.py:45) end the diverged restart instead.
@@ -138,7 +141,7 @@ class _RocheDopri5(torch.autograd.Function):
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         with torch.cuda.device(h.device):
             L.check(lib.hode_dopri5_bwd(d, _stream()), "hode_dopri5_bwd")
-        return gy0, (gth if need_th else None), gw, gb, None, None, None, None, None, None, None, None, None
+        return gy0, (gth if need_th else None), gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 def roche_dopri5(y0, theta, w, b, t, dosage, dose_times, rtol=1e-7, atol=1e-9, ablate=False, lanes_per_patient=0,
@@ -150,7 +153,7 @@ def roche_dopri5(y0, theta, w, b, t, dosage, dose_times, rtol=1e-7, atol=1e-9, a
     if dose_times.dim() != 2:
         dose_times = dose_times.reshape(y0.shape[0], -1)
     return _RocheDopri5.apply(y0, theta, w, b, t, dosage, dose_times.to(torch.float32), rtol, atol, bool(ablate),
-                              int(lanes_per_patient), int(max_steps), bool(detach_first_step))
+                              int(lanes_per_patient), int(max_steps), bool(detach_first_step), torch.is_grad_enabled())
 
 
 class _NeuralDopri5(torch.autograd.Function):
@@ -158,7 +161,7 @@ class _NeuralDopri5(torch.autograd.Function):
     attempt kernels of csrc/hode_neural_dopri5.hip; the backward accumulates the weight gradients on chip."""
 
     @staticmethod
-    def forward(ctx, y0, w1, b1, w2, b2, t, dosage, dose_times, rtol, atol, max_steps, detach_first_step):
+    def forward(ctx, y0, w1, b1, w2, b2, t, dosage, dose_times, rtol, atol, max_steps, detach_first_step, grad_enabled=True):
         _require_gpu(y0, w1, t, dosage, dose_times)
         lib = L.lib()
         B, D = y0.shape
@@ -166,7 +169,7 @@ class _NeuralDopri5(torch.autograd.Function):
         y0c, tc, dosc, dtc = _f32c(y0), _f32c(t), _f32c(dosage), _f32c(dose_times)
         w1c, b1c, w2c, b2c = _f32c(w1), _f32c(b1), _f32c(w2), _f32c(b2)
         h = torch.empty((T, B, D), device=y0.device, dtype=torch.float32)
-        no_tape = not any(ctx.needs_input_grad[:5])
+        no_tape = not (grad_enabled and any(ctx.needs_input_grad[:5]))  # see _RocheDopri5.forward
         steps = int(max_steps) if max_steps else ((1 << 20) if no_tape else 16 * T + 64)
         while True:
             status = torch.zeros(1, device=y0.device, dtype=torch.int32)
@@ -196,7 +199,7 @@ class _NeuralDopri5(torch.autograd.Function):
                 steps *= 4
                 continue
             break
-        last_stats.update(n_accepted=n_acc.value, n_rejected=n_rej.value)
+        last_stats.update(n_accepted=n_acc.value, n_rejected=n_rej.value, no_tape=no_tape, workspace_bytes=int(nbytes))
         if st:
             raise L.HodeError("hode dopri5: " + (_status_error(st) or "max_num_steps exceeded"))
         ctx.save_for_backward(h, tc, dosc, dtc, y0c, w1c, b1c, w2c, b2c, ws)
@@ -230,7 +233,7 @@ class _NeuralDopri5(torch.autograd.Function):
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         with torch.cuda.device(h.device):
             L.check(lib.hode_dopri5_bwd(d, _stream()), "hode_dopri5_bwd[neural]")
-        return gy0, gw1, gb1, gw2, gb2, None, None, None, None, None, None, None
+        return gy0, gw1, gb1, gw2, gb2, None, None, None, None, None, None, None, None
 
 
 #: latent dimensions the fused neural dopri5 kernels are compiled for (csrc/hode_neural_dopri5.hip)
@@ -242,4 +245,4 @@ def neural_dopri5(y0, w1, b1, w2, b2, t, dosage, dose_times, rtol=1e-7, atol=1e-
     if dose_times.dim() != 2:
         dose_times = dose_times.reshape(y0.shape[0], -1)
     return _NeuralDopri5.apply(y0, w1, b1, w2, b2, t, dosage, dose_times.to(torch.float32), rtol, atol, int(max_steps),
-                               bool(detach_first_step))
+                               bool(detach_first_step), torch.is_grad_enabled())

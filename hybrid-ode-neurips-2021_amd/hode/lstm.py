@@ -14,6 +14,29 @@ from . import _lib as L
 from .solver import _f32c, _ptr, _require_gpu, _stream
 
 
+#: measurement hook (bench.py): set to a list and every encoder call appends (name, start_event, end_event) for its three
+#: pieces -- "lstm_fwd" (pack kernels + lstm_fwd_kernel), "lstm_bwd" (BPTT kernel), "wgrad_gemm" (operand fill + split-K GEMM
+#: + fold).  None (the default) records nothing.
+timeline = None
+
+
+class _Span:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if timeline is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if timeline is not None:
+            self.e1.record()
+            timeline.append((self.name, self.e0, self.e1))
+        return False
+
+
 def _desc(x, a, mask, w_ih, w_hh, b_ih, b_hh, reverse, save_tape):
     T, B, obs = x.shape
     ad = 0 if a is None else a.shape[-1]
@@ -92,7 +115,7 @@ class _LstmEncode(torch.autograd.Function):
             L.check(lib.hode_lstm_fwd(d, _stream()), "hode_lstm_fwd")
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
-        with torch.cuda.device(x.device):
+        with torch.cuda.device(x.device), _Span("lstm_fwd"):
             L.check(lib.hode_lstm_fwd(d, _stream()), "hode_lstm_fwd")
         ctx.save_for_backward(xc, ac if ac is not None else xc, mc if mc is not None else xc, wi, wh, bi, bh, ws)
         ctx.flags = (ac is not None, mc is not None, bool(reverse))
@@ -118,14 +141,15 @@ class _LstmEncode(torch.autograd.Function):
         d.h_out, d.c_out = h_dummy.data_ptr(), h_dummy.data_ptr()  # unused by the backward, must be non-NULL
         d.grad_h_out, d.grad_gates, d.h_prev = gh.data_ptr(), dgates.data_ptr(), hprev.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        with torch.cuda.device(xc.device):
+        with torch.cuda.device(xc.device), _Span("lstm_bwd"):
             L.check(lib.hode_lstm_bwd(d, _stream()), "hode_lstm_bwd")
         dg2 = dgates.view(T * B, 4 * H)
-        if mc is not None:
-            torch.mul(xc, mc, out=hprev[:, :, :obs])   # the kernel leaves the first obs columns to the caller
-        else:
-            hprev[:, :, :obs].copy_(xc)
-        g = _splitk_tn(dg2, hprev.view(T * B, W))  # ONE product: [grad_w_ih | grad_w_hh | grad_b | 0]
+        with _Span("wgrad_gemm"):
+            if mc is not None:
+                torch.mul(xc, mc, out=hprev[:, :, :obs])   # the kernel leaves the first obs columns to the caller
+            else:
+                hprev[:, :, :obs].copy_(xc)
+            g = _splitk_tn(dg2, hprev.view(T * B, W))  # ONE product: [grad_w_ih | grad_w_hh | grad_b | 0]
         g_wih = g[:, :I].contiguous()
         g_whh = g[:, I:I + H].contiguous()
         g_b = g[:, I + H].contiguous()

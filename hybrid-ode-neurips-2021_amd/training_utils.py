@@ -2,8 +2,14 @@
 validation every ``test_freq`` iterations, best-on-disk checkpoint, early stopping, reload of the best checkpoint.
 
 Added for multi-GPU: when ``torch.distributed`` is initialised every rank draws the SAME minibatch (the
-generators are seeded identically), keeps its contiguous shard of the patients (``hode.parallel.shard_batch``) and the
-flat gradient bucket is averaged with one RCCL all-reduce per step (``hode.parallel.GradBucket``).  Every decision that
+host generators are seeded identically -- this holds for ``DataGeneratorRoche`` and ``DeviceFolds(index_rng="host")``; with
+``index_rng="device"`` it holds only if the ranks seed their device generators identically, otherwise the ranks train on
+independent minibatches, which is still a valid data-parallel step), keeps its contiguous shard of the patients
+(``hode.parallel.shard_batch``) and the flat gradient bucket is combined with one RCCL all-reduce per step
+(``hode.parallel.GradBucket``), each rank weighted by its share of the patients (ragged shards included).  The ranks also
+share torch's seed, so ``reparameterize`` draws the same eps block on every rank for DIFFERENT patients -- harmless (the
+draws are i.i.d. per patient either way); seed the ranks apart (``torch.manual_seed(seed + rank)`` after the data
+generators are built) if independent noise is wanted.  Every decision that
 ends or redirects the loop is taken on all-reduced quantities, so the ranks leave it together: a solver failure on one
 rank's shard travels in the bucket's flag slot and stops every rank before the optimiser step; the validation total is
 the mean of the per-rank totals (losses are normalised per local batch, reference model.py:1179,1188); rank 0 alone
@@ -22,7 +28,14 @@ def _trainable(optimizer):
 
 
 def _local(data):
-    return shard_batch(data) if is_distributed() else data
+    """This rank's contiguous shard of the batch and its share n_local / n_global of the patients.  Losses are normalised
+    per LOCAL batch (reference model.py:1179,1188), so the global-batch loss / gradient is the share-weighted sum of the
+    per-rank ones; with equal shards that is the plain mean, with ragged ones (batch_size % world != 0) it is not."""
+    if not is_distributed():
+        return data, 1.0
+    n = next(iter(data.values())).shape[1]
+    shard = shard_batch(data)
+    return shard, next(iter(shard.values())).shape[1] / float(n)
 
 
 def _validation_total(model, data_generator, batch_size):
@@ -30,9 +43,9 @@ def _validation_total(model, data_generator, batch_size):
     (reference :57-66).  Distributed: mean over ranks, and one rank's failure is every rank's."""
     total, failed = 0.0, 0.0
     for chunk in range(data_generator.val_size // batch_size):
-        data = _local(data_generator.get_split("val", batch_size, chunk))
+        data, share = _local(data_generator.get_split("val", batch_size, chunk))
         try:
-            total += model.loss(data).item()
+            total += model.loss(data).item() * share
         except RuntimeError as e:
             failed = 1.0
             print(e)
@@ -41,7 +54,7 @@ def _validation_total(model, data_generator, batch_size):
         dev = next(model.encoder.parameters()).device
         buf = torch.tensor([total, failed], dtype=torch.float64, device=dev)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        total, failed = float(buf[0]) / dist.get_world_size(), float(buf[1])
+        total, failed = float(buf[0]), float(buf[1])  # shares sum to 1 over the ranks: the sum IS the global-batch loss
     return total + (1e9 if failed else 0.0)
 
 
@@ -61,7 +74,7 @@ def variational_training_loop(niters, data_generator, model, batch_size, optimiz
             data = data_generator.get_mini_batch(train_fold, batch_size)
         else:
             data = data_generator.get_split(train_fold, batch_size, itr % train_chunk)
-        data = _local(data)
+        data, share = _local(data)
         optimizer.zero_grad()
         failure = None
         try:
@@ -80,7 +93,7 @@ def variational_training_loop(niters, data_generator, model, batch_size, optimiz
             else:
                 print(failure)
                 optimizer.zero_grad()
-            if bucket.all_reduce_mean(failed=failure is not None):
+            if bucket.all_reduce_mean(weight=share * dist.get_world_size(), failed=failure is not None):
                 break
         optimizer.step()
 

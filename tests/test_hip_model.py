@@ -211,3 +211,28 @@ def test_training_and_evaluation_run_from_device_resident_folds(tmp_path, capsys
     assert len(out) == 6 and all(v == v for v in out)
     hz = training_utils.evaluate_horizon(vi, folds, 16, 8, mc_itr=3)
     assert hz["rmse_x"].shape == (T - 8,)
+
+
+@pytest.mark.parametrize("roche,D", [(True, 12), (True, 4), (False, 12)])
+def test_dopri5_under_no_grad_with_parameters_takes_the_tape_less_path(roche, D):
+    """evaluate() and the validation pass integrate under `torch.no_grad()` with `ml_net`'s Parameters as inputs:
+    `needs_input_grad` is still True there (it mirrors requires_grad, not the grad mode), so the wrapper samples the grad
+    mode itself.  Under no_grad the solve must run with HODE_FLAG_NO_TAPE (two state rows instead of (16 T + 65) B D 4
+    bytes), give the same trajectory bit for bit, and with grad enabled keep the tape."""
+    from hode import adaptive, synth
+    dev = _dev()
+    obs, T, B, step = 40, 20, 64, synth.STEP
+    torch.manual_seed(3)
+    dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * step, step, roche=roche, method="dopri5", device=dev)
+    sol = synth.solver_inputs(B, T, D, seed=8)
+    z0, a = sol["z0"].to(dev), sol["actions"].to(dev)
+    assert any(p.requires_grad for p in dec.ode.parameters())
+    _, h_grad = dec(z0, a)
+    st_grad = dict(adaptive.last_stats)
+    with torch.no_grad():
+        _, h_eval = dec(z0, a)
+    st_eval = dict(adaptive.last_stats)
+    assert st_grad["no_tape"] is False and st_eval["no_tape"] is True
+    assert st_eval["workspace_bytes"] < st_grad["workspace_bytes"] // 8, (st_eval, st_grad)
+    assert st_eval["n_accepted"] == st_grad["n_accepted"] and st_eval["n_rejected"] == st_grad["n_rejected"]
+    assert torch.equal(h_grad.detach(), h_eval)

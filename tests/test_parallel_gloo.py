@@ -90,6 +90,7 @@ class _Folds:
     """Reference-style data generator (dataloader.py:322-341 signatures) over one seeded batch."""
 
     def __init__(self, B=8):
+        self.B = B
         self.data = _data(B=B)
         self.data["latents"] = torch.zeros(self.data["measurements"].shape[0], B, 8)
         self.train_size = self.val_size = B
@@ -102,7 +103,7 @@ class _Folds:
         return self.get_split(fold, batch_size, 0)
 
 
-def _train(vi, enc, dec, path, fail_at=None):
+def _train(vi, enc, dec, path, fail_at=None, B=8):
     import training_utils
     params = list(enc.parameters()) + list(dec.output_function.parameters()) + list(dec.ode.ml_net.parameters())
     opt = torch.optim.SGD(params, lr=1e-3)
@@ -125,17 +126,17 @@ def _train(vi, enc, dec, path, fail_at=None):
         return inner_step(*a, **k)
 
     opt.step = step
-    out = training_utils.variational_training_loop(6, _Folds(), vi, 8, opt, 2, path=path, shuffle=False)
+    out = training_utils.variational_training_loop(6, _Folds(B), vi, B, opt, 2, path=path, shuffle=False)
     return out, steps["n"], params
 
 
-def _loop_worker(rank, world, port, out_dir, fail_rank):
+def _loop_worker(rank, world, port, out_dir, fail_rank, B=8):
     for p in (ROOT, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     vi, enc, dec = _build()
-    (_, best, _), n_steps, params = _train(vi, enc, dec, out_dir + "/ckpt_", fail_at=3 if rank == fail_rank else None)
+    (_, best, _), n_steps, params = _train(vi, enc, dec, out_dir + "/ckpt_", fail_at=3 if rank == fail_rank else None, B=B)
     torch.save({"steps": n_steps, "best": best, "flat": torch.cat([p.detach().reshape(-1) for p in params])},
                os.path.join(out_dir, "loop_r%d.pt" % rank))
     dist.barrier()
@@ -152,6 +153,22 @@ def test_training_loop_two_ranks_matches_single_process(tmp_path):
     os.makedirs(str(tmp_path / "single"))
     (_, best, _), n_steps, params = _train(vi, enc, dec, str(tmp_path / "single") + "/ckpt_")
     assert n_steps == 6
+    torch.testing.assert_close(r0["flat"], torch.cat([p.detach().reshape(-1) for p in params]), rtol=2e-4, atol=1e-6)
+    assert abs(best - r0["best"]) <= 2e-4 * abs(best)
+
+
+def test_training_loop_two_ranks_ragged_shards_match_single_process(tmp_path):
+    """batch_size % world != 0 (7 patients over 2 ranks: 4 + 3): losses are normalised per LOCAL batch, so the loop weights
+    each rank's gradient and validation total by its share of the patients; a plain mean would not
+    reproduce the single-process run."""
+    port = _free_port()
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path), -1, 7), nprocs=2, join=True)
+    r0, r1 = torch.load(str(tmp_path / "loop_r0.pt")), torch.load(str(tmp_path / "loop_r1.pt"))
+    assert r0["steps"] == r1["steps"] == 6
+    assert torch.equal(r0["flat"], r1["flat"]) and r0["best"] == r1["best"]
+    vi, enc, dec = _build()
+    os.makedirs(str(tmp_path / "single"))
+    (_, best, _), n_steps, params = _train(vi, enc, dec, str(tmp_path / "single") + "/ckpt_", B=7)
     torch.testing.assert_close(r0["flat"], torch.cat([p.detach().reshape(-1) for p in params]), rtol=2e-4, atol=1e-6)
     assert abs(best - r0["best"]) <= 2e-4 * abs(best)
 
