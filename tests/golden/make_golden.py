@@ -7,14 +7,14 @@ Run in the build container only (``/root/reference`` does not exist on the GPU b
 
 What it does: imports the reference's ``model.py`` / ``dataloader.py`` from
 ``/root/reference`` and records inputs + outputs of the functions on the hot path
- as small ``.npz`` files.  The reference's ``model.py`` imports
+(G8 = the config-5 pipeline) as small ``.npz`` files.  The reference's ``model.py`` imports
 the third-party ``torchdiffeq`` at module level, which is not installed; an in-memory
 module of that name is registered whose ``odeint`` is this repo's CPU restatement
 (``oracle.solvers.odeint``).  Therefore:
 
 * G1-G4, G6, G7 (rhs, dose schedule, encoder, their autograd VJPs, generator batch) are
   pure reference arithmetic -- they PIN the oracle's rhs/encoder restatement.
-* G5 (``VariationalInference.loss``) pins everything AROUND the solver (set_action,
+* G5 (``VariationalInference.loss``) and G8 (``VariationalInferenceReal.loss`` with ``DecoderReal``) pin everything AROUND the solver (set_action,
   readout, masked SSE, KL) with the oracle solver in the loop; it does not pin the
   solver itself, which stays "parity unpinned" (see ``oracle/solvers.py``).
 
@@ -302,6 +302,64 @@ def gen_vi_loss():
     np.savez_compressed(os.path.join(HERE, "g5_vi_loss.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G8 (config 5: the real-data pipeline)
+def gen_vi_real():
+    """``DecoderReal.forward`` (model.py:833-862: ``t = arange(t0 - 1, t_max)``, ``output_function(h)[1:]``, ELU readout MLP)
+    + ``VariationalInferenceReal.loss`` (model.py:1223-1261: encoder on the first t0 steps over cat(x, a, s, t / max(mask)),
+    time-weighted masked SSE on x[t0:], analytic KL) + every parameter gradient, on DDW-shaped tensors (obs 24, statics 11,
+    D 20, encoder 37 -> 44, decoder hidden 43, t0 24), constructed as run_real.py:38-72 constructs them.  The oracle solver
+    is the torchdiffeq shim (same recipe as G5): this pins everything AROUND the solver on the real-data path."""
+    out = {}
+    gen = torch.Generator().manual_seed(808)
+    obs, act, stat, D, T, t0, B = 24, 1, 11, 20, 34, 24, 5
+    input_dim = obs + act + stat + 1
+    hidden = int((obs + act + stat) * 1.2)
+    cases = [("midpoint", 1, False, False), ("midpoint", 2, True, False), ("rk4", 1, False, False), ("midpoint", 1, True, True)]
+    for ci, (method, div, weight, elbo) in enumerate(cases):
+        torch.manual_seed(800 + ci)
+        enc = model.EncoderLSTMReal(input_dim, int(input_dim * 1.2), D, output_all=False, reverse=False, device=CPU)
+        dec = model.DecoderReal(obs, D, act, stat, hidden, T, 1, method=method, ode_step_size=1 / div, ode_type="hybrid",
+                                t0=t0, device=CPU)
+        vi = model.VariationalInferenceReal(enc, dec, elbo=elbo, t0=t0, weight=weight)
+        data = {"measurements": torch.randn(T, B, obs, generator=gen),
+                "actions": (torch.rand(T, B, act, generator=gen) < 0.15).float() * torch.rand(T, B, act, generator=gen),
+                "masks": (torch.rand(T, B, obs, generator=gen) < 0.5).float(),
+                "statics": torch.rand(1, B, stat, generator=gen).expand(T, B, stat).contiguous()}
+        torch.manual_seed(880 + ci)  # seeds the reparameterisation draw of the elbo case
+        loss = vi.loss(data)
+        for p in vi.parameters():
+            p.grad = None
+        loss.backward()
+        # what the decoder returned inside loss() (deterministic given z): run it once more for the record
+        with torch.no_grad():
+            a_in = torch.cat([data["actions"], data["statics"]], dim=-1)
+            mu, log_var = enc(data["measurements"][:t0], a_in[:t0], data["masks"][:t0])
+        pre = "c%d_" % ci
+        out[pre + "method"] = np.array(method)
+        out[pre + "meta"] = np.array([obs, act, stat, D, T, t0, B, div, int(weight), int(elbo), 880 + ci], dtype=np.int64)
+        for k, v in data.items():
+            out[pre + k] = npy(v)
+        out[pre + "loss"] = npy(loss)
+        out[pre + "mu"], out[pre + "log_var"] = npy(mu), npy(log_var)
+        if elbo:
+            torch.manual_seed(880 + ci)
+            z = enc.reparameterize(mu, log_var)
+        else:
+            z = mu
+        with torch.no_grad():
+            x_hat, h_hat = dec(z, data["actions"], data["statics"])
+        out[pre + "z"], out[pre + "x_hat"], out[pre + "h_hat"] = npy(z), npy(x_hat), npy(h_hat)
+        out[pre + "t"] = npy(dec.t)
+        out.update(sd_arrays(enc, pre + "enc_"))
+        out.update(sd_arrays(dec, pre + "dec_"))
+        for mod, tag in ((enc, "genc_"), (dec, "gdec_")):
+            for n, p in mod.named_parameters():
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                out[pre + tag + n.replace(".", "__")] = npy(g)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "g8_vi_real.npz"), **out)
+
+
 # ----------------------------------------------------------------------------- G7
 def gen_generator_batch():
     """100-patient dim8 batch from the reference generator (scipy LSODA latents): schema + loose known answer."""
@@ -338,6 +396,7 @@ if __name__ == "__main__":
     gen_encoder()
     gen_vi_loss()
     gen_generator_batch()
+    gen_vi_real()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
