@@ -942,9 +942,23 @@ __global__ __launch_bounds__(64) void split_fold_kernel(const float* __restrict_
   *dst = overwrite ? s : *dst + s;
 }
 
+// Occupancy bound the compiler is told about (and which it ENFORCES by padding the register count of the kernel descriptor,
+// tools/kernel_descriptor.py).  Forward: two workgroups may share a CU (176 registers): nothing changes up to one
+// workgroup per CU (10 000 - 12 288 patients: 51-52 us either way) and past it the second workgroup fills the issue slots
+// the first leaves empty -- 97.8 -> 77.3 us at 20 000 patients, 651 -> 507 us at 160 000 (tools/scale_probe.py, same-call
+// A/B against the pinned build, profiles/r03_v1_scale_probe.txt; four per CU measure the same as two).  Backward: one
+// workgroup per CU regardless -- it holds 94 KB of LDS and 216 registers x 5 waves; 2 waves per SIMD because the theta
+// wave shares one.
+#ifndef HODE_SPLIT_WPE_FWD
+#define HODE_SPLIT_WPE_FWD 2
+#endif
+#ifndef HODE_SPLIT_WPE_BWD
+#define HODE_SPLIT_WPE_BWD 2
+#endif
+
 // 4 waves (expert + 3 learned) or, with the tape and theta gradients, 5 (+ the theta wave, which shares a SIMD)
 template <int D, int METHOD, bool ABLATE, bool NEED_TH, bool TAPE>
-__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) void split_bwd_kernel(SplitBwdArgs a) {
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, HODE_SPLIT_WPE_BWD))) void split_bwd_kernel(SplitBwdArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
   if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true, TAPE>(a);
   else if (hill2) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, false, TAPE>(a);
@@ -952,7 +966,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 template <int D, int METHOD, bool ABLATE, bool TAPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_fwd_kernel(SplitArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, HODE_SPLIT_WPE_FWD))) void split_fwd_kernel(SplitArgs a) {
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
   if (hill2 && a.K == 1) split_fwd_body<D, METHOD, ABLATE, true, true, TAPE>(a);
   else if (hill2) split_fwd_body<D, METHOD, ABLATE, true, false, TAPE>(a);

@@ -119,3 +119,37 @@ def test_backward_every_tile_variant(nt, monkeypatch):
     (h * cot.to(dev)).sum().backward()
     for q, ref in zip(prm, (p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0)):
         assert float((q.grad.cpu().double() - ref.grad.double()).norm() / ref.grad.double().norm()) <= 1e-4
+
+
+@pytest.mark.parametrize("H", [5, 16, 24, 32, 40, 64, 70, 96, 100, 128, 144])
+def test_every_compiled_hidden_size_forward_and_backward(H):
+    """Padded hidden sizes 16, 32, ..., 160 (csrc/hode_lstm_tpw.hip; a hidden size in between runs on the next compiled one
+    with zero-padded units): `EncoderLSTM(input_dim, hidden_dim, ...)` accepts any hidden_dim up to 160 (reference
+    model.py:384-406 takes any).  Final state and every parameter gradient vs the oracle."""
+    from hode.lstm import lstm_encode
+    dev = _dev()
+    obs, B, T = 12, 37, 5
+    torch.manual_seed(H)
+    enc = EncoderLSTMOracle(obs + 1, H, 8)
+    x, a, m = _inputs(T, B, obs, seed=H)
+    cot = torch.randn(B, H, generator=torch.Generator().manual_seed(4))
+    h_o, _ = enc.final_hidden(x, a, m)
+    (h_o * cot).sum().backward()
+    p = enc.lstm
+    prm = [q.detach().clone().to(dev).requires_grad_(True) for q in (p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0)]
+    h = lstm_encode(x.to(dev), a.to(dev), m.to(dev), *prm, reverse=True)
+    assert (h.detach().cpu() - h_o.detach()).abs().max().item() <= 2e-5
+    (h * cot.to(dev)).sum().backward()
+    for q, ref, name in zip(prm, (p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0), ("w_ih", "w_hh", "b_ih", "b_hh")):
+        assert float((q.grad.cpu().double() - ref.grad.double()).norm() / ref.grad.double().norm()) <= 1e-4, (H, name)
+
+
+def test_hidden_size_above_the_largest_kernel_is_a_configuration_error():
+    import hode
+    from hode.lstm import lstm_final_state
+    dev = _dev()
+    lstm = torch.nn.LSTM(9, 176)
+    x, a, m = _inputs(3, 8, 8, seed=0)
+    with pytest.raises(hode.HodeConfigError, match="exceeds the largest compiled kernel"):
+        lstm_final_state(x.to(dev), a.to(dev), m.to(dev), lstm.weight_ih_l0.to(dev), lstm.weight_hh_l0.to(dev),
+                         lstm.bias_ih_l0.to(dev), lstm.bias_hh_l0.to(dev))
