@@ -299,8 +299,8 @@ int check_neural(const hode_solve_desc* d, bool bwd) {
   if (d->method < HODE_METHOD_EULER || d->method > HODE_METHOD_RK4_38)
     return hode::fail(HODE_E_UNSUPPORTED, "neural rhs: unknown fixed-grid method %d", d->method);
   if (d->batch <= 0 || d->n_times <= 0 || d->n_dose < 0) return hode::fail(HODE_E_SIZE, "bad sizes");
-  if (d->latent_dim != 6 && d->latent_dim != 8 && d->latent_dim != 12)
-    return hode::fail(HODE_E_UNSUPPORTED, "neural rhs: latent_dim %d has no compiled kernel (have 6, 8, 12)", d->latent_dim);
+  if (d->latent_dim < 4 || d->latent_dim > 14 || (d->latent_dim & 1))
+    return hode::fail(HODE_E_UNSUPPORTED, "neural rhs: latent_dim %d has no compiled kernel (have 4, 6, 8, 10, 12, 14)", d->latent_dim);
   if (d->hidden_dim != 10 * d->latent_dim)
     return hode::fail(HODE_E_SIZE, "neural rhs: hidden_dim %d != 10 * latent_dim (reference model.py:991-996)", d->hidden_dim);
   if (!d->t || !d->y0 || !d->dosage || !d->h || !d->w1 || !d->b1 || !d->w2 || !d->b2 || (d->n_dose > 0 && !d->dose_times))
@@ -357,6 +357,8 @@ int neural_rk(const hode_solve_desc* d, bool bwd, hipStream_t s) {
     if (!(env && env[0] == 't')) return launch_neural_mf(d, a, bwd, s);
   }
   const int D = d->latent_dim, HD = 10 * D;
+  if (D != 6 && D != 8 && D != 12)
+    return hode::fail(HODE_E_UNSUPPORTED, "neural rhs: the lane-per-patient layout (HODE_NEURAL_LAYOUT=t) is compiled for 6, 8, 12 only");
   hipLaunchKernelGGL(hode::transpose_w2_kernel, dim3((D * HD + 255) / 256), dim3(256), 0, s, d->w2, (float*)(ws + L.w2t), D, HD);
   if (int e = hode::hip_fail(hipGetLastError(), "transpose_w2 launch")) return e;
   switch (D) {

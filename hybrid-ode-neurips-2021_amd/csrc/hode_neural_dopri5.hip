@@ -605,11 +605,15 @@ int nd_bwd(const hode_solve_desc* d, hipStream_t s) {
 
 }  // namespace
 
+// Latent dimensions with a compiled kernel: the state [y, Dose, 1] must fit ONE 16-row tile (D + 2 <= 16); the reference's
+// simulation configs use 6 (its default, sim_config.py:25), 8 and 12.
+#define HODE_ND_DIMS(X) X(4) X(6) X(8) X(10) X(12) X(14)
+
 size_t neural_dopri5_workspace_bytes(const hode_solve_desc* d) {
   switch (d->latent_dim) {
-    case 6: return nd_layout<6>(d).total;
-    case 8: return nd_layout<8>(d).total;
-    case 12: return nd_layout<12>(d).total;
+#define HODE_ND_CASE(n) case n: return nd_layout<n>(d).total;
+    HODE_ND_DIMS(HODE_ND_CASE)
+#undef HODE_ND_CASE
   }
   return 0;
 }
@@ -617,10 +621,10 @@ size_t neural_dopri5_workspace_bytes(const hode_solve_desc* d) {
 int neural_dopri5_tape_offsets(const hode_solve_desc* d, size_t* out5) {
   NdLayout L;
   switch (d->latent_dim) {
-    case 6: L = nd_layout<6>(d); break;
-    case 8: L = nd_layout<8>(d); break;
-    case 12: L = nd_layout<12>(d); break;
-    default: return fail(HODE_E_UNSUPPORTED, "neural dopri5: latent_dim %d has no compiled kernel (have 6, 8, 12)", d->latent_dim);
+#define HODE_ND_CASE(n) case n: L = nd_layout<n>(d); break;
+    HODE_ND_DIMS(HODE_ND_CASE)
+#undef HODE_ND_CASE
+    default: return fail(HODE_E_UNSUPPORTED, "neural dopri5: latent_dim %d has no compiled kernel (have 4, 6, 8, 10, 12, 14)", d->latent_dim);
   }
   out5[0] = L.ctrl + kNdInitOffset; out5[1] = L.tape_t; out5[2] = L.tape_dt; out5[3] = L.tape_j; out5[4] = L.tape_y;
   return 0;
@@ -631,11 +635,11 @@ int neural_dopri5(const hode_solve_desc* d, bool bwd, hipStream_t s) {
     return fail(HODE_E_UNSUPPORTED, "neural dopri5: hidden_dim %d != 10 * latent_dim (model.py:992)", d->hidden_dim);
   if (!d->w1 || !d->b1 || !d->w2 || !d->b2) return fail(HODE_E_NULL, "neural dopri5: w1 / b1 / w2 / b2 required");
   switch (d->latent_dim) {
-    case 6: return bwd ? nd_bwd<6>(d, s) : nd_fwd<6>(d, s);
-    case 8: return bwd ? nd_bwd<8>(d, s) : nd_fwd<8>(d, s);
-    case 12: return bwd ? nd_bwd<12>(d, s) : nd_fwd<12>(d, s);
+#define HODE_ND_CASE(n) case n: return bwd ? nd_bwd<n>(d, s) : nd_fwd<n>(d, s);
+    HODE_ND_DIMS(HODE_ND_CASE)
+#undef HODE_ND_CASE
   }
-  return fail(HODE_E_UNSUPPORTED, "neural dopri5: latent_dim %d has no compiled kernel (have 6, 8, 12)", d->latent_dim);
+  return fail(HODE_E_UNSUPPORTED, "neural dopri5: latent_dim %d has no compiled kernel (have 4, 6, 8, 10, 12, 14)", d->latent_dim);
 }
 
 }  // namespace hode

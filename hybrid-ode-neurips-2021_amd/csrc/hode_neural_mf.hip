@@ -207,16 +207,22 @@ int launch_neural_mf_d(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, 
 size_t neural_mf_partial_bytes(const hode_solve_desc* d) {
   const size_t nw = (d->batch + 15) / 16;
   switch (d->latent_dim) {
+    case 4: return nw * NeuralGradAcc<4>::NP * sizeof(float);
     case 6: return nw * NeuralGradAcc<6>::NP * sizeof(float);
     case 8: return nw * NeuralGradAcc<8>::NP * sizeof(float);
+    case 10: return nw * NeuralGradAcc<10>::NP * sizeof(float);
+    case 14: return nw * NeuralGradAcc<14>::NP * sizeof(float);
     default: return nw * NeuralGradAcc<12>::NP * sizeof(float);
   }
 }
 
 int launch_neural_mf(const hode_solve_desc* d, const NeuralArgs& a, bool bwd, hipStream_t s) {
-  switch (d->latent_dim) {
+  switch (d->latent_dim) {   // check_neural admits 4, 6, ..., 14: [y, Dose, 1] fits one 16-row tile
+    case 4: return launch_neural_mf_d<4>(d, a, bwd, s);
     case 6: return launch_neural_mf_d<6>(d, a, bwd, s);
     case 8: return launch_neural_mf_d<8>(d, a, bwd, s);
+    case 10: return launch_neural_mf_d<10>(d, a, bwd, s);
+    case 14: return launch_neural_mf_d<14>(d, a, bwd, s);
     default: return launch_neural_mf_d<12>(d, a, bwd, s);
   }
 }

@@ -503,30 +503,47 @@ struct F4 {  // the expert wave's 4 components as two packed pairs
 HODE_DEV F4 operator*(float s, const F4& v) { return F4{s * v.a, s * v.b}; }
 HODE_DEV F4 vfma(float s, const F4& x, const F4& y) { return F4{vfma(s, x.a, y.a), vfma(s, x.b, y.b)}; }
 
+// LDS of one backward workgroup, declared ONCE in the kernel and handed to the body instantiation that runs (a `__shared__`
+// array inside split_bwd_body exists once per instantiation: three of them -- HILL2 / K1 variants -- made 94 KB of 31).
+//   CW (c-wave, with the tape): the transposed product of the expert cotangent, c_q = sum_j W[j][q] u_j, runs on a wave of
+//   its own between the learned waves (which publish u through `uring`) and the expert wave, which then lags the learned
+//   waves by TWO iterations instead of one: every ring gets a third slot, slot(step) = (learned iteration of the step) % RD.
+template <int D, bool CW>
+struct SplitBwdShared {
+  static constexpr int RD = CW ? 3 : 2;   // ring depth
+  static constexpr int M = D - 4;
+  float yring[RD][4][kSplitPatients][4];        // expert stage states
+  // learned block -> expert cotangent; row kSplitPatients stays zero: the expert wave's 16 spare lanes read it, so that
+  // their (masked) cotangent stays exactly zero without a per-stage multiply
+  float cring[RD][4][kSplitPatients + 1][4];
+  // Dose(t_s) [0..3] and dDose/dkel [4..7] of the 4 stages; written by the expert wave when it re-integrates, by the
+  // learned waves (stage q by quad lane q) when the stage states come from the tape
+  float dring[RD][kSplitPatients][8];
+  float gring[RD][4][kSplitPatients + 1][4];    // THW: stage cotangents for the theta wave; row kSplitPatients: zeros
+  float tdring[RD][kSplitPatients][8];          // THW: the doses of the step the expert wave has just adjoined
+  float uring[CW ? RD : 1][4][CW ? kSplitPatients : 1][CW ? M : 1];   // CW: u = g (1 - s^2) of the learned rows, per stage
+  float red[4][4][M * D + M];                   // epilogue: per-row partial sums of every gradient entry of a wave
+};
+
 template <int D, int METHOD, bool ABLATE, bool HILL2, bool NEED_TH, bool K1, bool TAPE>
-HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
+HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh) {
   constexpr int NS = sp_stages<METHOD>();
   typedef MlRows<D> Ml;
   typedef typename Ml::Own Own;
   constexpr int M = Ml::M, MR = Ml::MR, DP = Ml::DP, MP = Ml::MP;
-  __shared__ __attribute__((aligned(16))) float yring[2][4][kSplitPatients][4];   // expert stage states
-  // learned block -> expert cotangent; row kSplitPatients stays zero: the expert wave's 16 spare lanes read it, so that
-  // their (masked) cotangent stays exactly zero without a per-stage multiply
-  __shared__ __attribute__((aligned(16))) float cring[2][4][kSplitPatients + 1][4];
-  // Dose(t_s) [0..3] and dDose/dkel [4..7] of the 4 stages; written by the expert wave when it re-integrates, by the
-  // learned waves (stage q by quad lane q) when the stage states come from the tape
-  __shared__ __attribute__((aligned(16))) float dring[2][kSplitPatients][8];
   // THW: the 13 (15) theta-gradient accumulations of every stage run on a FIFTH wave, one iteration behind the expert wave
   // and off its cotangent chain (they are 40 % of its instructions, two v_log per stage among them): the expert wave hands
   // over the stage cotangents g_s through gring, the theta wave reads the stage states from the forward's tape and gets
   // the doses forwarded (tdring).  Only with the tape (without it the stage states exist nowhere but in the expert wave).
   constexpr bool THW = TAPE && NEED_TH;
-  __shared__ __attribute__((aligned(16))) float gring[2][4][kSplitPatients + 1][4];   // row kSplitPatients: zeros
-  // the doses of the step the expert wave has just adjoined (Dose(t_s) [0..3], dDose/dkel [4..7]), forwarded to the theta
-  // wave: dring itself is refilled by the learned waves while the theta wave would read it
-  __shared__ __attribute__((aligned(16))) float tdring[2][kSplitPatients][8];
-  // epilogue: the 4 per-row (16-lane) partial sums of every gradient entry of a wave, summed across rows from here
-  __shared__ float red[4][4][M * D + M];
+  // CW: see SplitBwdShared.  The learned waves' loop loses the M fmas + the LDS write of c_q per stage (-32 of ~350
+  // instructions per step; they bound the adjoint) and gains one write of u.
+  constexpr bool CW = TAPE;
+  constexpr int RD = SplitBwdShared<D, TAPE>::RD;
+  constexpr int EL = CW ? 2 : 1;           // iterations the expert wave lags the learned waves
+  constexpr int CWAVE = THW ? 5 : 4;       // wave index of the c-wave
+  auto& yring = sh.yring; auto& cring = sh.cring; auto& dring = sh.dring; auto& gring = sh.gring;
+  auto& tdring = sh.tdring; auto& uring = sh.uring; auto& red = sh.red;
   extern __shared__ float tg[];  // time grid, see sp_stage_grid
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -534,13 +551,27 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
   const RocheTheta th = load_theta(a.theta, ABLATE);
   const size_t row = (size_t)a.B * D;
   const int T = a.T;
+  // Iterations: the learned waves handle step T-2-k in iteration k (k <= T-2), the expert wave adjoins step T-k+EL-2 in
+  // iteration k (EL <= k <= T+EL-2).  All waves run the same NIT iterations (one barrier each).
+  const int NIT = T + EL - 1;
   sp_stage_grid(tg, a.t, a.T);  // visible after the __syncthreads that precedes both pipelines' loops
 #ifdef HODE_SPLIT_STAMPS
-#define HODE_SSTAMP(k) if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[(size_t)wave * a.T + (k)] = __builtin_amdgcn_s_memtime();
-  if (a.dbg && blockIdx.x < 8 && lane == 0) a.dbg[(size_t)5 * a.T + blockIdx.x * 8 + wave] = __builtin_amdgcn_s_getreg(63492);  // HW_ID: SIMD in bits 5:4
+#define HODE_SSTAMP(k) if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[(size_t)wave * (a.T + 2) + (k)] = __builtin_amdgcn_s_memtime();
+  if (a.dbg && blockIdx.x < 8 && lane == 0) a.dbg[(size_t)6 * (a.T + 2) + blockIdx.x * 8 + wave] = __builtin_amdgcn_s_getreg(63492);  // HW_ID: SIMD in bits 5:4
 #else
 #define HODE_SSTAMP(k)
 #endif
+  // the time loops are unrolled by RD through a generic lambda: S = k % RD is a compile-time constant, so every ring offset
+  // is an immediate
+  auto run = [&](auto&& iter) {
+    for (int k = 0; k < NIT; k += RD) {
+      iter(k, IC<0>{});
+      if (k + 1 < NIT) iter(k + 1, IC<1>{});
+      if constexpr (RD == 3) {
+        if (k + 2 < NIT) iter(k + 2, IC<2>{});
+      }
+    }
+  };
 
   if (wave == 0) {
     // ================================================================== expert wave
@@ -556,7 +587,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     ds.tau0 = K1 ? ds.taus[0] : 0.f;
     const float ln_ec50 = log_f32(th.ec50);
     const int cslot = mine ? lane : kSplitPatients;
-    if (lane < 32) (&cring[lane >> 4][(lane >> 2) & 3][kSplitPatients][0])[lane & 3] = 0.f;
+    if (lane < 16 * RD) (&cring[lane >> 4][(lane >> 2) & 3][kSplitPatients][0])[lane & 3] = 0.f;
     const unsigned lane_h = (unsigned)p * D, lane_t = (unsigned)p * 4;  // 32-bit lane offsets on wave-uniform bases
     MlSlice<4, 1> none;
     MlColSlice<4, 1> nonec;
@@ -564,7 +595,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     acc.zero();
     float own1[1] = {0.f};
 
-    // (a): stage states + doses of step m into ring buffer `par`.  Without a tape the stages are re-integrated; with
+    // (a): stage states + doses of step m into ring slot `par`.  Without a tape the stages are re-integrated; with
     // one, fetch() issues the loads an iteration's worth of work ahead of publish().
     float tp[4][4];  // plain floats: an array of float4 is not promoted to registers
     auto fetch = [&](int m) {
@@ -624,12 +655,13 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       publish(T - 2, 0);
     }
     __syncthreads();
-    auto e_iter = [&](int k, auto PAR) {
-      constexpr int par = decltype(PAR)::value;  // == (k - 1) & 1 == (k + 1) & 1: the buffer (b) reads and (a) refills
+    auto e_iter = [&](int k, auto SI) {
+      constexpr int S = decltype(SI)::value;         // == k % RD
+      constexpr int par = (S + 1) % RD;              // slot of the step (b) adjoins == the slot (a) refills for iteration k + 1
       if (T - 3 - k >= 0) fetch(T - 3 - k);
-      if (k >= 1) {
-        // ---- (b) adjoint of step m = T-1-k
-        const int m = T - 1 - k;
+      if (k >= EL && k <= T + EL - 2) {
+        // ---- (b) adjoint of step m = T-k+EL-2 (the learned waves handled it in iteration k-EL: slot (k-EL) % RD == par)
+        const int m = T - k + EL - 2;
         const float dt = tg[m + 1] - tg[m];
         float Y[4][4];
         F4 cs[4];
@@ -640,8 +672,8 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
           dv[0].v = d0.x; dv[1].v = d0.y; dv[2].v = d0.z; dv[3].v = d0.w;
           dv[0].dk = d1.x; dv[1].dk = d1.y; dv[2].dk = d1.z; dv[3].dk = d1.w;
           if constexpr (THW) {
-            *reinterpret_cast<float4*>(&tdring[par ^ 1][slot][0]) = d0;
-            *reinterpret_cast<float4*>(&tdring[par ^ 1][slot][4]) = d1;
+            *reinterpret_cast<float4*>(&tdring[S][slot][0]) = d0;
+            *reinterpret_cast<float4*>(&tdring[S][slot][4]) = d1;
           }
         }
 #pragma unroll
@@ -657,7 +689,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
           const float g[4] = {gs.a.x, gs.a.y, gs.b.x, gs.b.y};
           float av[4];
           if constexpr (THW) {
-            if (mine) *reinterpret_cast<float4*>(&gring[par ^ 1][s][slot][0]) = make_float4(g[0], g[1], g[2], g[3]);
+            if (mine) *reinterpret_cast<float4*>(&gring[S][s][slot][0]) = make_float4(g[0], g[1], g[2], g[3]);
           }
           roche_vjp<4, 1, ABLATE, HILL2, NEED_TH && !THW>(th, none, nonec, ln_ec50, dv[s], Y[s], own1, g, 0, av, acc);
           F4 r = cs[s];
@@ -674,10 +706,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       HODE_SSTAMP(k)
       __syncthreads();
     };
-    for (int k = 0; k < T; k += 2) {
-      e_iter(k, IC<1>{});
-      if (k + 1 < T) e_iter(k + 1, IC<0>{});
-    }
+    run(e_iter);
     if (live) *reinterpret_cast<float4*>(a.grad_y0 + (size_t)p * D) = make_float4(lam.a.x, lam.a.y, lam.b.x, lam.b.y);
     // theta partials: 16-lane row sums by DPP rotations, the 4 rows joined through LDS (in-order within the wave)
     if constexpr (!THW) {
@@ -697,7 +726,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     const int p = min(b0 + slot, a.B - 1);
     const int gslot = mine ? lane : kSplitPatients;   // spare lanes read the zero row: their contributions are exactly zero
     const float ln_ec50 = log_f32(th.ec50);
-    if (lane < 32) (&gring[lane >> 4][(lane >> 2) & 3][kSplitPatients][0])[lane & 3] = 0.f;
+    if (lane < 16 * RD) (&gring[lane >> 4][(lane >> 2) & 3][kSplitPatients][0])[lane & 3] = 0.f;
     const unsigned lane_h = (unsigned)p * D, lane_t = (unsigned)p * 4;
     float dth[kNTheta];
 #pragma unroll
@@ -713,7 +742,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
         tp[s][0] = u.x; tp[s][1] = u.y; tp[s][2] = u.z; tp[s][3] = u.w;
       }
     };
-    // the theta terms of step m; stages in the order the expert wave's adjoint visits them (3, 2, 1, 0), so that every
+    // the theta terms of a step; stages in the order the expert wave's adjoint visits them (3, 2, 1, 0), so that every
     // accumulator sees its terms in the same order as when the expert wave accumulates them itself
     auto theta_step = [&](int gpar) {
       const float4 d0 = *reinterpret_cast<const float4*>(&tdring[gpar][slot][0]);
@@ -730,18 +759,17 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       }
     };
     __syncthreads();  // the expert wave's prologue
-    auto t_iter = [&](int k, auto PAR) {
-      constexpr int gpar = decltype(PAR)::value;  // == (k - 1) & 1: what the expert wave wrote in iteration k - 1
-      if (k >= 2) theta_step(gpar);
-      if (k >= 1 && T - k - 1 >= 0) fetch(T - k - 1);
+    auto t_iter = [&](int k, auto SI) {
+      constexpr int S = decltype(SI)::value;
+      constexpr int gpar = (S + RD - 1) % RD;   // what the expert wave wrote in iteration k - 1 (its step T-k+EL-1)
+      if (k >= EL + 1) theta_step(gpar);
+      // the stage states of the step the expert wave adjoins in THIS iteration (processed here in the next one)
+      if (k >= EL && T - k + EL - 2 >= 0) fetch(T - k + EL - 2);
       HODE_SSTAMP(k)
       __syncthreads();
     };
-    for (int k = 0; k < T; k += 2) {
-      t_iter(k, IC<1>{});
-      if (k + 1 < T) t_iter(k + 1, IC<0>{});
-    }
-    if (T >= 2) theta_step((T - 1) & 1);
+    run(t_iter);
+    if (T >= 2) theta_step((NIT - 1) % RD);
 #pragma unroll
     for (int i = 0; i < kNTheta; ++i) {
       const float v = row_sum(dth[i]);
@@ -750,6 +778,60 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane < kNTheta)
       a.part_th[(size_t)blockIdx.x * kNTheta + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+  } else if (CW && wave == CWAVE) {
+    // ================================================================== c-wave (one patient per lane)
+    // c_q = sum_j W[j][q] u_j for the four expert components q, per stage: the same fma chain in the same order as the
+    // learned waves formed it before (MR == 2: one chain over j; MR == 1: even and odd j in two chains joined by one add),
+    // so every output stays bit-identical to the tape-less kernel.
+    const int slot = lane < kSplitPatients ? lane : 0;
+    const bool mine = lane < kSplitPatients;
+    float wq[M][4];   // W[j][q]: wave-uniform
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wq[j][q] = a.w1[j * D + q];
+    __syncthreads();  // the expert wave's prologue
+    auto c_iter = [&](int k, auto SI) {
+      constexpr int S = decltype(SI)::value;
+      constexpr int cpar = (S + RD - 1) % RD;   // the step the learned waves handled in iteration k - 1
+      if (k >= 1 && k - 1 <= T - 2) {
+        float u[NS][M];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+          for (int j4 = 0; j4 < M; j4 += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(&uring[cpar][s][slot][j4]);
+            u[s][j4] = v.x; u[s][j4 + 1] = v.y; u[s][j4 + 2] = v.z; u[s][j4 + 3] = v.w;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all ring reads of the step up front
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          float c[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if constexpr (MR == 2) {
+              float cq = 0.f;
+#pragma unroll
+              for (int j = 0; j < M; ++j) cq = __builtin_fmaf(wq[j][q], u[s][j], cq);
+              c[q] = cq;
+            } else {
+              float cx = 0.f, cy = 0.f;
+#pragma unroll
+              for (int jp = 0; jp < MP; ++jp) {
+                cx = __builtin_fmaf(wq[2 * jp][q], u[s][2 * jp], cx);
+                cy = __builtin_fmaf(wq[2 * jp + 1][q], u[s][2 * jp + 1], cy);
+              }
+              c[q] = cx + cy;
+            }
+          }
+          if (mine) *reinterpret_cast<float4*>(&cring[cpar][s][slot][0]) = make_float4(c[0], c[1], c[2], c[3]);
+        }
+      }
+      HODE_SSTAMP(k)
+      __syncthreads();
+    };
+    run(c_iter);
   } else {
     // ================================================================== learned waves (quad layout, own components)
     const int q = lane & 3;
@@ -759,7 +841,8 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
     const float lv = live ? 1.0f : 0.0f;
     Ml ml;
     ml.load(a.w1, a.b1, q);
-    // transposed operands of a = W^T u.  wc: column q of W (the expert component this lane reports to the expert wave).
+    // transposed operands of a = W^T u.  wc: column q of W (the expert component this lane reports to the expert wave;
+    // unused with the c-wave).
     // MR == 2: wc[j] scalars, wtp[j] = (W[j][own0], W[j][own1]) (row-paired, the result is the Own pair);
     // MR == 1: wc[jp] = (W[2jp][q], W[2jp+1][q]), wtp[jp] = (W[2jp][own], W[2jp+1][own]) (paired over the rows j).
     typename Ml::Elem wc[Ml::NU];
@@ -805,8 +888,8 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       }
     }
     __syncthreads();  // the expert wave's prologue fills ring 0
-    auto m_iter = [&](int k, auto PAR) {
-      constexpr int par = decltype(PAR)::value;  // == k & 1
+    auto m_iter = [&](int k, auto SI) {
+      constexpr int par = decltype(SI)::value;  // == k % RD
       if (k <= T - 2) {
         const int m = T - 2 - k;
         const float t0 = tg[m], t1 = tg[m + 1];
@@ -830,7 +913,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
         __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
-        if constexpr (TAPE) {  // the expert wave adjoins this step next iteration: its doses, stage q by quad lane q
+        if constexpr (TAPE) {  // the expert wave adjoins this step EL iterations later: its doses, stage q by quad lane q
           const DoseVal dq = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel);  // lanes q >= NS: unread
           dring[par][slot][q] = dq.v;
           if constexpr (NEED_TH) dring[par][slot][4 + q] = dq.dk;
@@ -849,6 +932,10 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
           const Own u = gs * vfma(-so[s], so[s], vsplat<Own>(1.0f));
           db += u;
           Ml::outer_acc(dw, u, Y[s]);
+          if constexpr (CW) {   // the c-wave forms c_q from it in the next iteration
+            if constexpr (MR == 2) *reinterpret_cast<float2*>(&uring[par][s][slot][2 * q]) = make_float2(u.x, u.y);
+            else uring[par][s][slot][q] = u;
+          }
           typename Ml::Gath uf;
           Ml::gather(u, uf.v);
           if constexpr (MR == 2) {
@@ -856,21 +943,21 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
             f2 av = splat2(0.f), av1 = splat2(0.f);  // two chains, see MlRows::rhs
 #pragma unroll
             for (int j = 0; j < M; j += 2) {
-              cq = __builtin_fmaf(wc[j], uf.v[j], cq);
+              if constexpr (!CW) cq = __builtin_fmaf(wc[j], uf.v[j], cq);
               av = vfma(wtp[j], uf.v[j], av);
-              cq = __builtin_fmaf(wc[j + 1], uf.v[j + 1], cq);
+              if constexpr (!CW) cq = __builtin_fmaf(wc[j + 1], uf.v[j + 1], cq);
               av1 = vfma(wtp[j + 1], uf.v[j + 1], av1);
             }
-            cring[par][s][slot][q] = cq;
+            if constexpr (!CW) cring[par][s][slot][q] = cq;
             return av + av1;
           } else {
             f2 c2 = splat2(0.f), a2 = splat2(0.f);
 #pragma unroll
             for (int jp = 0; jp < MP; ++jp) {
-              c2 = vfma(wc[jp], uf.v[jp], c2);
+              if constexpr (!CW) c2 = vfma(wc[jp], uf.v[jp], c2);
               a2 = vfma(wtp[jp], uf.v[jp], a2);
             }
-            cring[par][s][slot][q] = hsum(c2);
+            if constexpr (!CW) cring[par][s][slot][q] = hsum(c2);
             return hsum(a2);
           }
         });
@@ -879,10 +966,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a) {
       HODE_SSTAMP(k)
       __syncthreads();
     };
-    for (int k = 0; k < T; k += 2) {
-      m_iter(k, IC<0>{});
-      if (k + 1 < T) m_iter(k + 1, IC<1>{});
-    }
+    run(m_iter);
     if (live) Ml::store_own(a.grad_y0 + (size_t)p * D, q, lam);
     // weight-gradient partials of this wave's 16 patients: sum over the 4 quads of a 16-lane row with two DPP
     // rotations per entry, join the 4 rows through LDS, store the M*D + M entries with coalesced lanes
@@ -956,13 +1040,14 @@ __global__ __launch_bounds__(64) void split_fold_kernel(const float* __restrict_
 #define HODE_SPLIT_WPE_BWD 2
 #endif
 
-// 4 waves (expert + 3 learned) or, with the tape and theta gradients, 5 (+ the theta wave, which shares a SIMD)
+// 4 waves (expert + 3 learned); with the tape + the c-wave, and with theta gradients + the theta wave: up to 6
 template <int D, int METHOD, bool ABLATE, bool NEED_TH, bool TAPE>
-__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(1, HODE_SPLIT_WPE_BWD))) void split_bwd_kernel(SplitBwdArgs a) {
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(1, HODE_SPLIT_WPE_BWD))) void split_bwd_kernel(SplitBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) SplitBwdShared<D, TAPE> sh;
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
-  if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true, TAPE>(a);
-  else if (hill2) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, false, TAPE>(a);
-  else split_bwd_body<D, METHOD, ABLATE, false, NEED_TH, false, TAPE>(a);
+  if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true, TAPE>(a, sh);
+  else if (hill2) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, false, TAPE>(a, sh);
+  else split_bwd_body<D, METHOD, ABLATE, false, NEED_TH, false, TAPE>(a, sh);
 }
 
 template <int D, int METHOD, bool ABLATE, bool TAPE>
@@ -1002,10 +1087,10 @@ int split_bwd_method(const hode_solve_desc* d, const hode::SplitBwdArgs& a, hipS
   const size_t lds = (size_t)(d->n_times + 3) * sizeof(float);  // the time grid (n_times <= kSplitMaxT)
 #define HODE_SPLIT_BWD(M)                                                                                        \
   if (d->need_theta_grad) {                                                                                      \
-    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, true>), grid, dim3(320), lds, s, a); \
+    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, true>), grid, dim3(384), lds, s, a); \
     else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, true, false>), grid, block, lds, s, a);          \
   } else {                                                                                                       \
-    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, true>), grid, block, lds, s, a);   \
+    if (a.tape) hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, true>), grid, dim3(320), lds, s, a); \
     else hipLaunchKernelGGL((hode::split_bwd_kernel<D, M, ABLATE, false, false>), grid, block, lds, s, a);         \
   }
   switch (d->method) {

@@ -236,8 +236,9 @@ class _NeuralDopri5(torch.autograd.Function):
         return gy0, gw1, gb1, gw2, gb2, None, None, None, None, None, None, None, None
 
 
-#: latent dimensions the fused neural dopri5 kernels are compiled for (csrc/hode_neural_dopri5.hip)
-NEURAL_DIMS = (6, 8, 12)
+#: latent dimensions the fused neural dopri5 kernels are compiled for (csrc/hode_neural_dopri5.hip: [y, Dose, 1] must fit
+#: one 16-row MFMA tile); the reference's simulation configs use 6, 8 and 12
+NEURAL_DIMS = (4, 6, 8, 10, 12, 14)
 
 
 def neural_dopri5(y0, w1, b1, w2, b2, t, dosage, dose_times, rtol=1e-7, atol=1e-9, max_steps=0, detach_first_step=False):

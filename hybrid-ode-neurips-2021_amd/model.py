@@ -226,38 +226,19 @@ class NeuralODE(nn.Module):
         from hode import neural
         if method == "dopri5":
             from hode import adaptive
-            if self.latent_dim in adaptive.NEURAL_DIMS and y0.is_cuda:
-                # the reference's default for --method=neural (sim_config.py:50): fused MFMA attempt kernels
-                return adaptive.neural_dopri5(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight,
-                                              self.ml_net[2].bias, t, self.dosage, self.times, rtol=rtol, atol=atol)
-            return _eager_dopri5(self, y0, t, rtol, atol, options)
+            if self.latent_dim not in adaptive.NEURAL_DIMS:
+                raise hode.HodeConfigError("hode: NeuralODE with method='dopri5' is compiled for latent dimensions %s (got %d); "
+                                           "there is no torch-eager path in the product"
+                                           % (", ".join(str(d) for d in adaptive.NEURAL_DIMS), self.latent_dim))
+            # the reference's default for --method=neural (sim_config.py:50): fused MFMA attempt kernels
+            return adaptive.neural_dopri5(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight,
+                                          self.ml_net[2].bias, t, self.dosage, self.times, rtol=rtol, atol=atol)
         from hode import substep
         perturb = bool(options.pop("perturb", False))
         return substep.solve_with_step_size(
             lambda grid: neural.neural_solve(y0, self.ml_net[0].weight, self.ml_net[0].bias, self.ml_net[2].weight,
                                              self.ml_net[2].bias, grid, self.dosage, self.times, method=method, perturb=perturb),
             t, options.pop("step_size", None))
-
-
-_EAGER_DOPRI5_ANNOUNCED = set()
-
-
-def _eager_dopri5(ode, y0, t, rtol, atol, options):
-    """(NeuralODE, "dopri5") at a latent dimension the fused kernels are not compiled for (they cover 6, 8, 12).  The solve runs
-    as torch GPU launches per stage (``hode.adaptive_eager``: torchdiffeq's dopri5 semantics, discrete adjoint over the
-    accepted-step tape) -- said once per rhs class, never silently, and never on the CPU."""
-    from hode import adaptive_eager
-    if not y0.is_cuda:
-        raise hode.HodeConfigError("hode: %s needs its tensors on a HIP device (there is no CPU path)" % type(ode).__name__)
-    name = type(ode).__name__
-    if name not in _EAGER_DOPRI5_ANNOUNCED:
-        _EAGER_DOPRI5_ANNOUNCED.add(name)
-        import warnings
-        warnings.warn("hode: %s with method='dopri5' has no fused kernel; integrating with torch GPU launches per stage "
-                      "(hode.adaptive_eager).  The fixed-grid methods (rk4, midpoint, euler) use the HIP kernels." % name)
-    for key in ("step_size", "perturb", "step_t"):  # fixed-grid options: torchdiffeq's dopri5 ignores them with a warning
-        options.pop(key, None)
-    return adaptive_eager.odeint_dopri5(ode, y0, t, rtol=rtol, atol=atol)
 
 
 class RocheExpertDecoder(nn.Module):
@@ -398,7 +379,7 @@ class RocheODEReal(nn.Module):
         from hode import real
         if method == "dopri5":
             # DecoderReal hands dopri5 a `step_t` grid (model.py:826: steps are cut at the hourly dose switches); that
-            # option's semantics are restated neither by the oracle nor by hode.adaptive_eager.  real.sh:15 uses midpoint.
+            # option's semantics are not restated by the oracle.  real.sh:15 uses midpoint.
             raise hode.HodeConfigError("hode: RocheODEReal is built for the fixed-grid methods (euler, midpoint, rk4); "
                                  "dopri5 with options['step_t'] is not supported")
         from hode import substep

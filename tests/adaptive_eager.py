@@ -1,4 +1,8 @@
-"""Dormand-Prince 5(4) for right-hand sides that have no fused adaptive kernel (NeuralODE).
+"""TEST INFRASTRUCTURE (not part of the product, never imported by it): Dormand-Prince 5(4) with the rhs as the module's own
+torch launches per stage -- an independent cross-check of the fused adaptive kernels (tests/test_hip_neural.py,
+tests/test_adaptive_eager.py).  Until round 3 this module served (NeuralODE, "dopri5") at latent dimensions without a fused
+kernel from inside the product; the kernels now cover every even dimension 4..14 and the product raises HodeConfigError
+elsewhere.
 
 ``torchdiffeq.odeint(func, y0, t, rtol=, atol=, method="dopri5")`` semantics (the reference's default solver,
 sim_config.py:50, reached with the neural rhs by ``run_simulation --method=neural``; call site model.py:1116) on the
@@ -25,7 +29,7 @@ output grid; failures are ``HodeError`` (a ``RuntimeError``: non-finite state, d
 import numpy as np
 import torch
 
-from . import _lib as L
+from hode import _lib as L
 
 _ALPHA = (1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
 _BETA = (

@@ -1,11 +1,11 @@
-"""`hode.adaptive_eager` (dopri5 for the right-hand side without a fused adaptive kernel: NeuralODE) against
+"""`tests/adaptive_eager.py` (dopri5 for the right-hand side without a fused adaptive kernel: NeuralODE) against
 the CPU oracle's torchdiffeq-semantics dopri5.  The module is plain torch, so its arithmetic is pinned here on the CPU; the
 model classes only hand it HIP tensors (`tests/test_hip_neural.py::test_neural_dopri5_through_the_mirror`)."""
 import pytest
 import torch
 
 import model
-from hode import adaptive_eager as ae
+import adaptive_eager as ae
 from oracle.rhs import NeuralRHS, RocheRHS
 from oracle.solvers import odeint as oracle_odeint
 

@@ -143,9 +143,10 @@ def test_neural_dopri5_fused_kernels_vs_oracle_and_tape_replay(D, N):
 
 
 def test_neural_dopri5_matches_the_eager_cross_check_and_edge_shapes():
-    """hode.adaptive_eager (torch launches per stage: torchdiffeq's semantics written out) stays as a cross-check of the
+    """tests/adaptive_eager.py (torch launches per stage: torchdiffeq's semantics written out) stays as a cross-check of the
     fused kernels; one output time / one patient / a batch one past a wave."""
-    from hode import adaptive, adaptive_eager, synth
+    import adaptive_eager
+    from hode import adaptive, synth
     dev = _dev()
     D, T = 8, 12
     for N in (1, 17):
@@ -173,19 +174,17 @@ def test_neural_dopri5_matches_the_eager_cross_check_and_edge_shapes():
 
 def test_neural_dopri5_through_the_mirror():
     """`run_simulation --method=neural` keeps the reference's default solver, dopri5 (sim_config.py:50): the mirror's
-    NeuralODE integrates with the fused kernels (no warning) at the compiled latent dimensions and says so once when it
-    has to fall back to `hode.adaptive_eager` at another one.  Same weights and inputs through the CPU oracle:
-    trajectories and gradients."""
-    import warnings
-
+    NeuralODE integrates with the fused kernels at every compiled latent dimension (even, 4..14; the reference's configs
+    use 6, 8, 12) and raises a configuration error elsewhere -- there is no torch-eager path in the product.  Same weights
+    and inputs through the CPU oracle: trajectories and gradients."""
+    import hode
     import model
     from hode import adaptive, synth
     from oracle import vi as ovi
     dev = _dev()
     obs, T, B = 40, 12, 20
-    for D, fused in ((8, True), (10, False)):
+    for D in (4, 6, 8, 10, 14):
         torch.manual_seed(0)
-        model._EAGER_DOPRI5_ANNOUNCED.discard("NeuralODE")
         dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * synth.STEP, synth.STEP, roche=False, method="dopri5", device=dev)
         dec_o = ovi.DecoderOracle(obs, D, (T - 1) * synth.STEP, synth.STEP, roche=False, method="dopri5")
         dec_o.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
@@ -194,12 +193,8 @@ def test_neural_dopri5_through_the_mirror():
         zo = inp["z0"].clone().requires_grad_(True)
         cot = torch.randn(T, B, obs)
         adaptive.last_stats.update(n_accepted=-1)
-        with warnings.catch_warnings(record=True) as seen:
-            warnings.simplefilter("always")
-            x_hat, h = dec(z, inp["actions"].to(dev))
-            dec(z.detach(), inp["actions"].to(dev))
-        assert sum("no fused kernel" in str(w.message) for w in seen) == (0 if fused else 1)
-        assert (adaptive.last_stats["n_accepted"] > 0) == fused
+        x_hat, h = dec(z, inp["actions"].to(dev))
+        assert adaptive.last_stats["n_accepted"] > 0
         x_o, h_o = dec_o(zo, inp["actions"])
         assert (h.detach().cpu() - h_o.detach()).abs().max().item() <= 5e-6
         (x_hat * cot.to(dev)).sum().backward()
@@ -208,4 +203,37 @@ def test_neural_dopri5_through_the_mirror():
         for (n, p), (_, po) in zip(dec.named_parameters(), dec_o.named_parameters()):
             if po.grad is None or float(po.grad.abs().max()) == 0.0:
                 continue
-            assert _rel(p.grad.cpu(), po.grad) <= 2e-4, n
+            assert _rel(p.grad.cpu(), po.grad) <= 2e-4, (D, n)
+    dec = model.RocheExpertDecoder(obs, 16, 1, (T - 1) * synth.STEP, synth.STEP, roche=False, method="dopri5", device=dev)
+    inp = synth.solver_inputs(B, T, 16, seed=2)
+    with pytest.raises(hode.HodeConfigError, match="4, 6, 8, 10, 12, 14"):
+        dec(inp["z0"].to(dev), inp["actions"].to(dev))
+
+
+@pytest.mark.parametrize("D", [4, 10, 14])
+def test_neural_fixed_grid_at_the_added_latent_dimensions(D):
+    """rk4 / midpoint / euler with the NeuralODE rhs at the latent dimensions added in round 3, through the mirror."""
+    import model
+    from hode import synth
+    from oracle import vi as ovi
+    dev = _dev()
+    obs, T, B = 24, 10, 21
+    for method in ("rk4", "midpoint", "euler"):
+        torch.manual_seed(1)
+        dec = model.RocheExpertDecoder(obs, D, 1, (T - 1) * synth.STEP, synth.STEP, roche=False, method=method, device=dev)
+        dec_o = ovi.DecoderOracle(obs, D, (T - 1) * synth.STEP, synth.STEP, roche=False, method=method)
+        dec_o.load_state_dict({k: v.cpu() for k, v in dec.state_dict().items()})
+        inp = synth.solver_inputs(B, T, D, seed=4)
+        z = inp["z0"].to(dev).requires_grad_(True)
+        zo = inp["z0"].clone().requires_grad_(True)
+        cot = torch.randn(T, B, obs)
+        x_hat, h = dec(z, inp["actions"].to(dev))
+        x_o, h_o = dec_o(zo, inp["actions"])
+        assert (h.detach().cpu() - h_o.detach()).abs().max().item() <= 2e-5
+        (x_hat * cot.to(dev)).sum().backward()
+        (x_o * cot).sum().backward()
+        assert _rel(z.grad.cpu(), zo.grad) <= 2e-4
+        for (n, p), (_, po) in zip(dec.named_parameters(), dec_o.named_parameters()):
+            if po.grad is None or float(po.grad.abs().max()) == 0.0:
+                continue
+            assert _rel(p.grad.cpu(), po.grad) <= 2e-4, (D, method, n)

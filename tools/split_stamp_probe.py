@@ -1,12 +1,14 @@
 """Which wave of a split-adjoint workgroup arrives last at the step barrier (s_memtime stamps, block 0).
-Needs: HODE_SPLIT_FLAGS="-fno-slp-vectorize -DHODE_SPLIT_STAMPS" python build_hip.py   (product builds carry no stamps)"""
+Needs a stamp build (product builds carry no stamps):
+    python build_hip.py --variant stamps --unit-flags hode_rk_split="-DHODE_SPLIT_STAMPS"
+    HODE_LIBRARY=.../hode/libhode_stamps.so python tools/split_stamp_probe.py"""
 import os, sys, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neurips-2021_amd"))
 import bench
 dev = torch.device("cuda:0")
 T = bench.T
-dbg = torch.zeros(5 * T + 64, dtype=torch.int64, device=dev)
+dbg = torch.zeros(6 * (T + 2) + 64, dtype=torch.int64, device=dev)
 os.environ["HODE_SPLIT_DBG_PTR"] = hex(dbg.data_ptr())
 dbgf = torch.zeros(4 * T, dtype=torch.int64, device=dev)
 os.environ["HODE_SPLIT_FWD_DBG_PTR"] = hex(dbgf.data_ptr())
@@ -16,16 +18,16 @@ for _ in range(3):
     plan.step()
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy().astype(np.int64)
-s = raw[:5 * T].reshape(5, T)
-hw = raw[5 * T:].reshape(8, 8)[:, :5]
-print('SIMD of waves 0..4 (expert, learned x3, helper) in workgroups 0..7:', [[int((v >> 4) & 3) for v in row] for row in hw])
-names = ["expert", "learned 1", "learned 2", "learned 3", "theta"]
+s = raw[:6 * (T + 2)].reshape(6, T + 2)[:, :T]
+hw = raw[6 * (T + 2):].reshape(8, 8)[:, :6]
+print('SIMD of waves 0..5 (expert, learned x3, theta, c-wave) in workgroups 0..7:', [[int((v >> 4) & 3) for v in row] for row in hw])
+names = ["expert", "learned 1", "learned 2", "learned 3", "theta", "c-wave"]
 ks = np.arange(10, T - 10)
 arr = s[:, ks]                      # arrival of each wave at the barrier of iteration k
 last = arr.max(axis=0)
 period = np.diff(last)
 print("step period (last arrival to last arrival): median %d cycles = %.0f ns" % (np.median(period), np.median(period) / 2.4))
-for w in range(5):
+for w in range(6):
     slack = last - arr[w]
     print("%-10s arrives %5d cycles (median) before the last wave; last in %2d %% of the steps" % (names[w], np.median(slack), 100 * np.mean(arr[w] == last)))
 print("forward kernel:")
