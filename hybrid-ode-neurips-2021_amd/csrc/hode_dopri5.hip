@@ -168,10 +168,12 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
   if (int e = dp_dispatch_dim(d, L, a, s)) return e;
   L.phase = 2;
   L.waves_per_block = kAttemptWavesPerBlock;
+#ifdef HODE_DP_EXPERIMENTS   // diagnostic builds only: a stray environment variable must not change the shipped launch structure
   if (const char* env = getenv("HODE_DP_WPB")) {  // tuning
     const int v = atoi(env);
     if (v >= 1 && v <= 4) L.waves_per_block = v;
   }
+#endif
   {
     // which rhs specialisation the attempts run (both Hill exponents == 2 is the shipped configuration) is a property of
     // the parameters: read the two exponents back once, under the init kernels, instead of on the device in every launch
@@ -184,13 +186,15 @@ extern "C" int hode_dopri5_fwd(const hode_solve_desc* d, void* stream) {
   int attempt = 0;
   // every attempt either accepts (<= max_steps of those) or shrinks dt by >= 5x towards underflow: a generous bound
   const long long max_attempts = 64LL * ((long long)d->max_steps + 64);
-  // Opt-in (HODE_DP_PERSIST=1, quad layout): the whole attempt loop in one persistent launch (dp_persist_body_own: state in
+  // Experiment builds only (-DHODE_DP_EXPERIMENTS, then HODE_DP_PERSIST=1, quad layout): the whole attempt loop in one persistent launch (dp_persist_body_own: state in
   // registers, one hop through memory per attempt instead of a kernel boundary).  Correct and bounded, but MEASURED SLOWER on
   // this part -- 7.0 us per attempt against 5.7 (tools/dp_persist_probe.py): a fence-free, atomics-free all-to-all exchange
   // across 8 XCDs still costs ~5 us, more than the ~3.8 us the kernel boundary costs.  Kept as the
   // reproducible form of that measurement; a launch that cannot assemble its waves falls back to the loop below.
   bool persist = false;
+#ifdef HODE_DP_EXPERIMENTS
   if (const char* env = getenv("HODE_DP_PERSIST")) persist = atoi(env) != 0 && L.lpp == 4 && a.n_waves <= hode::kDpMaxPersistWaves;
+#endif
   if (persist) {
     if (int e = hode::hip_fail(hipMemsetAsync(a.slots, 0, (size_t)2 * a.n_waves * sizeof(unsigned long long), s), "slot clear")) return e;
     L.phase = 6;

@@ -1,4 +1,5 @@
-"""A/B of the dopri5 forward: persistent attempt loop (default) vs one launch per attempt (HODE_DP_PERSIST=0), same process;
+"""(needs an experiment build: HODE_DP_FLAGS=-DHODE_DP_EXPERIMENTS python build_hip.py --force)
+A/B of the dopri5 forward: persistent attempt loop (default) vs one launch per attempt (HODE_DP_PERSIST=0), same process;
 checks that both leave the SAME tape and trajectory."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
