@@ -27,6 +27,9 @@
 //   * adjoint with the tape and theta gradients: a FIFTH wave accumulates the 13 (15) expert-parameter gradients one
 //     iteration behind the expert wave, off its cotangent chain (stage cotangents and doses through two LDS rings, stage
 //     states from the tape); it shares a SIMD with the expert wave (100 -> 80 us together with the tape);
+//   * adjoint with the tape: the transposed product c_q = sum_j W[j][q] u_j (the learned block's share of the expert cotangent)
+//     runs on a wave of its own between the learned waves and the expert wave, which then lags two iterations; rings three
+//     deep (81.0 -> 79.4 us, bit-identical);
 //   * the time grid sits in LDS (dynamic shared memory, hence n_times <= 8192 for this layout);
 //   * time loops unrolled by two through a generic lambda so that ring parities are immediates; all ring reads of a step
 //     are issued up front and pinned with sched_barrier; per-step stores are unpredicated (lanes beyond the batch hold

@@ -67,8 +67,9 @@ extern "C" {
                             set, and hand the same, untouched buffer to both.  Costs 16 (stages-1) B per patient and grid
                             interval of extra HBM traffic in each direction, plus, for rk4, 8 (D-4) B for the learned
                             block's last two stage derivatives; layouts without a tape ignore the flag.  With the tape
-                            and need_theta_grad the adjoint kernel runs 5 waves per 48 patients (the fifth accumulates
-                            the expert-parameter gradients); every output is bit-identical to the tape-less path. */
+                            the adjoint kernel runs 5 waves per 48 patients (the fifth forms the learned block's contribution
+                            to the expert cotangent), 6 with need_theta_grad (one more accumulates the expert-parameter
+                            gradients); every output is bit-identical to the tape-less path. */
 
 #define HODE_FLAG_DETACH_FIRST_STEP 8 /* hode_dopri5_bwd: treat the first step size as a constant.  torchdiffeq computes
                                         Hairer's dt_0 from y0, f0, f1 with autograd ON, so the reference's loss.backward()
