@@ -560,9 +560,12 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh)
   sp_stage_grid(tg, a.t, a.T);  // visible after the __syncthreads that precedes both pipelines' loops
 #ifdef HODE_SPLIT_STAMPS
 #define HODE_SSTAMP(k) if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[(size_t)wave * (a.T + 2) + (k)] = __builtin_amdgcn_s_memtime();
+// phase stamps inside an iteration of learned wave 3 (alone on its SIMD): [T + 2][8] behind the barrier stamps and the HW_ID block
+#define HODE_PSTAMP(k, ph) { __builtin_amdgcn_sched_barrier(0); if (a.dbg && blockIdx.x == 0 && wave == 3 && lane == 0) a.dbg[(size_t)6 * (a.T + 2) + 64 + (size_t)(k) * 8 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
   if (a.dbg && blockIdx.x < 8 && lane == 0) a.dbg[(size_t)6 * (a.T + 2) + blockIdx.x * 8 + wave] = __builtin_amdgcn_s_getreg(63492);  // HW_ID: SIMD in bits 5:4
 #else
 #define HODE_SSTAMP(k)
+#define HODE_PSTAMP(k, ph)
 #endif
   // the time loops are unrolled by RD through a generic lambda: S = k % RD is a compile-time constant, so every ring offset
   // is an immediate
@@ -894,6 +897,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh)
     auto m_iter = [&](int k, auto SI) {
       constexpr int par = decltype(SI)::value;  // == k % RD
       if (k <= T - 2) {
+        HODE_PSTAMP(k, 0)
         const int m = T - 2 - k;
         const float t0 = tg[m], t1 = tg[m + 1];
         const float dt = t1 - t0;
@@ -916,6 +920,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh)
 #pragma unroll
         for (int s = 0; s < NS; ++s) e[s] = *reinterpret_cast<const float4*>(&yring[par][s][slot][0]);
         __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
+        HODE_PSTAMP(k, 1)
         if constexpr (TAPE) {  // the expert wave adjoins this step EL iterations later: its doses, stage q by quad lane q
           const DoseVal dq = ds.at(sp_stage_time<METHOD>(t0, t1, a.perturb, q), th.kel);  // lanes q >= NS: unread
           dring[par][slot][q] = dq.v;
@@ -931,7 +936,9 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh)
           else so[s] = ml.rhs(Y[s]);
         }
         // ---- adjoint of the stages
+        HODE_PSTAMP(k, 2)
         sp_adjoint_step<METHOD>(lam, dt, [&](int s, Own gs) {
+          HODE_PSTAMP(k, 6 - s)
           const Own u = gs * vfma(-so[s], so[s], vsplat<Own>(1.0f));
           db += u;
           Ml::outer_acc(dw, u, Y[s]);
@@ -965,6 +972,7 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh)
           }
         });
         lam = vfma(lv, gh, lam);
+        HODE_PSTAMP(k, 7)
       }
       HODE_SSTAMP(k)
       __syncthreads();

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "hybrid-ode-neur
 import bench
 dev = torch.device("cuda:0")
 T = bench.T
-dbg = torch.zeros(6 * (T + 2) + 64, dtype=torch.int64, device=dev)
+dbg = torch.zeros(6 * (T + 2) + 64 + 8 * (T + 2), dtype=torch.int64, device=dev)
 os.environ["HODE_SPLIT_DBG_PTR"] = hex(dbg.data_ptr())
 dbgf = torch.zeros(4 * T, dtype=torch.int64, device=dev)
 os.environ["HODE_SPLIT_FWD_DBG_PTR"] = hex(dbgf.data_ptr())
@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 raw = dbg.cpu().numpy().astype(np.int64)
 s = raw[:6 * (T + 2)].reshape(6, T + 2)[:, :T]
-hw = raw[6 * (T + 2):].reshape(8, 8)[:, :6]
+hw = raw[6 * (T + 2):6 * (T + 2) + 64].reshape(8, 8)[:, :6]
 print('SIMD of waves 0..5 (expert, learned x3, theta, c-wave) in workgroups 0..7:', [[int((v >> 4) & 3) for v in row] for row in hw])
 names = ["expert", "learned 1", "learned 2", "learned 3", "theta", "c-wave"]
 ks = np.arange(10, T - 10)
@@ -30,6 +30,15 @@ print("step period (last arrival to last arrival): median %d cycles = %.0f ns" %
 for w in range(6):
     slack = last - arr[w]
     print("%-10s arrives %5d cycles (median) before the last wave; last in %2d %% of the steps" % (names[w], np.median(slack), 100 * np.mean(arr[w] == last)))
+ph = raw[6 * (T + 2) + 64:].reshape(T + 2, 8)[10:T - 10]
+names_ph = ["iteration start -> ring reads issued", "-> stage states + recompute done (adjoint starts)", "-> VJP of stage 3 entered",
+            "-> VJP of stage 2 entered", "-> VJP of stage 1 entered", "-> VJP of stage 0 entered", "-> adjoint done"]
+if ph[:, 0].any():   # phase slots: 0 start, 1 reads, 2 adjoint start, 3 = VJP s=3, 4 = s=2, 5 = s=1, 6 = s=0, 7 end
+    print("learned wave 3, phases of an iteration (median cycles; the stamps themselves add ~40 % to the step):")
+    for i, nm in enumerate(names_ph):
+        print("   %-52s %5d" % (nm, np.median(ph[:, i + 1] - ph[:, i])))
+    print("   %-52s %5d" % ("whole iteration body (start -> adjoint done)", np.median(ph[:, 7] - ph[:, 0])))
+    print("   %-52s %5d" % ("adjoint done -> next iteration start (barrier)", np.median(ph[1:, 0] - ph[:-1, 7])))
 print("forward kernel:")
 sf = dbgf.cpu().numpy().astype(np.int64).reshape(4, T)
 ks = np.arange(10, T - 10)
