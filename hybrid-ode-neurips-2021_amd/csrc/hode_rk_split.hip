@@ -1050,10 +1050,13 @@ __global__ __launch_bounds__(64) void split_fold_kernel(const float* __restrict_
 #ifndef HODE_SPLIT_WPE_BWD
 #define HODE_SPLIT_WPE_BWD 2
 #endif
+#ifndef HODE_SPLIT_WPE_BWD_MIN
+#define HODE_SPLIT_WPE_BWD_MIN 1   // experiment builds: 3 forces <= 168 registers so that two backward workgroups fit a CU
+#endif
 
 // 4 waves (expert + 3 learned); with the tape + the c-wave, and with theta gradients + the theta wave: up to 6
 template <int D, int METHOD, bool ABLATE, bool NEED_TH, bool TAPE>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(1, HODE_SPLIT_WPE_BWD))) void split_bwd_kernel(SplitBwdArgs a) {
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(HODE_SPLIT_WPE_BWD_MIN, HODE_SPLIT_WPE_BWD))) void split_bwd_kernel(SplitBwdArgs a) {
   __shared__ __attribute__((aligned(16))) SplitBwdShared<D, TAPE> sh;
   const bool hill2 = ABLATE || (a.theta[0] == 2.0f && a.theta[1] == 2.0f);
   if (hill2 && a.K == 1) split_bwd_body<D, METHOD, ABLATE, true, NEED_TH, true, TAPE>(a, sh);

@@ -41,8 +41,9 @@ if __name__ == "__main__":
         sys.exit(0)
     libdir = os.path.join(ROOT, "hybrid-ode-neurips-2021_amd", "hode")
     out = {}
-    for tag, lib in (("product (1 workgroup / CU)", "libhode.so"), ("B: forward <= 2 workgroups / CU", "libhode_wpeB.so"),
-                     ("C: forward <= 4 workgroups / CU", "libhode_wpeC.so"), ("product again", "libhode.so")):
+    for tag, lib in (("product (forward <= 2 workgroups / CU, backward 1)", "libhode.so"), ("B: forward <= 2 workgroups / CU", "libhode_wpeB.so"),
+                     ("C: forward <= 4 workgroups / CU", "libhode_wpeC.so"),
+                     ("bwd3: backward forced to <= 168 registers (two workgroups / CU fit)", "libhode_bwd3.so"), ("product again", "libhode.so")):
         path = os.path.join(libdir, lib)
         if not os.path.exists(path):
             print("skip %s (%s not built)" % (tag, lib))
