@@ -4,7 +4,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r03c10
+O=gpurun_out/r03_final
 mkdir -p $O
 timeout -k 10 1000 python3 -m pytest tests -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"; tail -6 $O/tests.log | cut -c 1-300
 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"

@@ -4,7 +4,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r03c1
+O=gpurun_out/r03_ramp
 mkdir -p $O
 python3 tools/ramp_probe.py > $O/ramp.txt 2> $O/ramp.err || { tail -5 $O/ramp.err; exit 1; }
 echo "ramp done"
