@@ -294,6 +294,8 @@ def full_training_step(dev, iters=10, cpu=True, n_cpu=1000, dist=None, rank=0):
         mu, lv = enc(data["measurements"], data["actions"], data["masks"])
         (mu.sum() + lv.sum()).backward()
 
+    host_ms = []
+
     def timed(fn):
         for _ in range(3):
             fn()
@@ -303,6 +305,7 @@ def full_training_step(dev, iters=10, cpu=True, n_cpu=1000, dist=None, rank=0):
         t0 = time.perf_counter()
         for _ in range(iters):
             fn()
+        host_ms.append((time.perf_counter() - t0) / iters * 1e3)   # time the HOST needed to enqueue a step
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -330,10 +333,12 @@ def full_training_step(dev, iters=10, cpu=True, n_cpu=1000, dist=None, rank=0):
         pieces[name] = {"ms": t_ms, "gflop": fl[name] / 1e9, "achieved": fl[name] / (t_ms * 1e-3) / 1e12,
                         "frac": fl[name] / (t_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
     ach = fl["total"] / (ms_enc * 1e-3) / 1e12
-    out = {"ms": ms, "trajectories_per_s": N_PER_GPU * world / ms * 1e3, "n_ranks": world,
+    out = {"ms": ms, "host_enqueue_ms": host_ms[0], "trajectories_per_s": N_PER_GPU * world / ms * 1e3, "n_ranks": world,
            "per_gpu_trajectories_per_s": N_PER_GPU / ms * 1e3,
            "what": "EncoderLSTM(81->160, fp32 MFMA) + rk4 solve + fused readout / masked SSE + MC-KL, fwd+bwd%s + Adam update, "
-                   "%d patients per GPU" % ("" if dist is None else " + rccl all-reduce(AVG) of the flat gradient bucket", N_PER_GPU),
+                   "%d patients per GPU; the batch is the same tensors at every step, so set_action's dose schedule comes from its identity "
+                   "cache after the first step (no host synchronisation inside the step: host_enqueue_ms)"
+                   % ("" if dist is None else " + rccl all-reduce(AVG) of the flat gradient bucket", N_PER_GPU),
            "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel + lstm_bwd_kernel (v_mfma_f32_16x16x4_f32) + weight-gradient GEMM (hipBLASLt)",
                         "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
                         "traffic": None,
@@ -738,12 +743,17 @@ def main():
     stub = bool(os.environ.get("HODE_BENCH_STUB"))   # CPU test of the N > 1 control flow (gloo, StubPlan)
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)  # does not return
-    if world > 1 and not os.environ.get("HODE_BENCH_CHILD") and not args.no_guard:
+    # HODE_BENCH_FORCE_SUPERVISOR: rehearse the supervisor / fallback machinery at world size 1 (all a one-GPU box allows)
+    if (world > 1 or os.environ.get("HODE_BENCH_FORCE_SUPERVISOR")) and "RANK" in os.environ and not os.environ.get("HODE_BENCH_CHILD") \
+            and not args.no_guard:
         if args.no_graph and args.grad_exchange in ("auto", "graph"):
             args.grad_exchange = "sync"
         supervise(args, ["graph", "overlap"] if args.grad_exchange == "auto" else [args.grad_exchange])  # does not return
     if args.grad_exchange == "auto":
         args.grad_exchange = "graph" if world > 1 else "overlap"
+    if os.environ.get("HODE_BENCH_FAIL_GRAPH") and args.grad_exchange == "graph" and os.environ.get("HODE_BENCH_CHILD"):
+        log("HODE_BENCH_FAIL_GRAPH: leaving with the guard's exit code (rehearsal of the fallback)")
+        os._exit(GUARD_EXIT)
     attempt = int(os.environ.get("HODE_BENCH_ATTEMPT", "0"))
     failed_modes = [m for m in os.environ.get("HODE_BENCH_FAILED_MODES", "").split(",") if m]
 

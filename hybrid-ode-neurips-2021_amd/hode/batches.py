@@ -69,6 +69,27 @@ class DeviceFolds:
         tr, va = self.train_size, self.val_size
         cut = lambda lo, hi: {k: getattr(self, k)[:, lo:hi].contiguous() for k in self.fields}
         self.data_train, self.data_val, self.data_test = cut(0, tr), cut(tr, tr + va), cut(tr + va, self.n_sample)
+        self._schedules = {}
+
+    # The dose schedule of a fold (dosage, grid indices of the doses), derived ONCE: ``RocheODE.set_action`` needs the dose
+    # count on the host, i.e. host synchronisations in the middle of every training step; a batch's schedule is a gather of
+    # the fold's.  Attached to the batch's action tensor as ``hode_schedule`` (model.RocheODE.set_action reads it).  Folds
+    # whose patients have unequal dose counts get none (set_action then raises like the reference).
+    def _schedule(self, fold):
+        if fold not in self._schedules:
+            a = self._fold(fold)["actions"]
+            try:
+                from .solver import dose_schedule_index
+                self._schedules[fold] = dose_schedule_index(a) if a.shape[2] == 1 and a.shape[1] > 0 else None
+            except RuntimeError:
+                self._schedules[fold] = None
+        return self._schedules[fold]
+
+    def _attach(self, batch, fold, pick):
+        sched = self._schedule(fold)
+        if sched is not None:
+            batch["actions"].hode_schedule = (pick(sched[0]), pick(sched[1]))
+        return batch
 
     def set_device(self, device):
         if torch.device(device) != self.device:
@@ -84,10 +105,12 @@ class DeviceFolds:
         print("train_size", self.train_size)
         print("n_sample", self.n_sample)
         self.data_train = {k: v[:, :self.train_size].contiguous() for k, v in self.data_train.items()}
+        self._schedules.pop("train", None)
 
     def set_val_size(self, n_val):
         self.val_size = int(n_val)
         self.data_val = {k: v[:, :n_val].contiguous() for k, v in self.data_val.items()}
+        self._schedules.pop("val", None)
 
     def _fold(self, fold):
         assert fold in ("train", "val", "test")
@@ -101,12 +124,12 @@ class DeviceFolds:
     def get_mini_batch(self, fold, batch_size):
         data = self._fold(fold)
         idx = self._get_index_random(data["measurements"].shape[1], batch_size)
-        return {k: v.index_select(1, idx) for k, v in data.items()}
+        return self._attach({k: v.index_select(1, idx) for k, v in data.items()}, fold, lambda x: x.index_select(0, idx))
 
     def get_split(self, fold, batch_size, chunk=0):
         data = self._fold(fold)
         lo, hi = chunk * batch_size, (chunk + 1) * batch_size
         n = data["measurements"].shape[1]
         if lo == 0 and hi >= n:
-            return dict(data)  # the whole fold: the resident tensors themselves
-        return {k: v[:, lo:hi].contiguous() for k, v in data.items()}
+            return self._attach(dict(data), fold, lambda x: x)  # the whole fold: the resident tensors themselves
+        return self._attach({k: v[:, lo:hi].contiguous() for k, v in data.items()}, fold, lambda x: x[lo:hi])

@@ -34,7 +34,12 @@ def shard_batch(data: dict, rank: int = None, world: int = None) -> dict:
         rank, world = dist.get_rank(), dist.get_world_size()
     n = next(iter(data.values())).shape[1]
     lo, hi = shard_bounds(n, rank, world)
-    return {k: v[:, lo:hi] for k, v in data.items()}
+    out = {k: v[:, lo:hi] for k, v in data.items()}
+    for k, v in data.items():   # a batch source's precomputed dose schedule (hode.batches.DeviceFolds) travels with the shard
+        sched = getattr(v, "hode_schedule", None)
+        if sched is not None:
+            out[k].hode_schedule = tuple(x[lo:hi] for x in sched)
+    return out
 
 
 class GradBucket:
@@ -51,6 +56,7 @@ class GradBucket:
         # one extra slot behind the gradients: the "this rank's step failed" flag of the training loop rides along
         self._buf = torch.zeros(self.numel + 1, device=first.device, dtype=torch.float32)
         self.flat = self._buf[:self.numel]
+        self._flag = self._buf[self.numel:]
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -84,7 +90,7 @@ class GradBucket:
         flag travels in the same collective and the call returns whether ANY rank failed -- one host read-back, so that
         all ranks leave the training loop in the same iteration; otherwise it returns the flat gradient view."""
         self._gather(weight)
-        self._buf[self.numel] = 1.0 if failed else 0.0
+        self._flag.fill_(1.0 if failed else 0.0)   # (a kernel: `buf[i] = python_float` is a synchronous host-to-device copy)
         if is_distributed():
             if dist.get_backend() == "gloo":  # gloo has no AVG
                 dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)

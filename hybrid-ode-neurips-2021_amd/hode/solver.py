@@ -42,6 +42,20 @@ def pack_theta(scalars, device):
     return vec
 
 
+def dose_schedule_index(action):
+    """(dosage (B,), dose_index (B, K) int64) of an action tensor (T, B, 1): what ``RocheODE.set_action`` (reference
+    model.py:495-507) derives, with the grid indices left unscaled.  Requires equal dose counts per patient, like the
+    reference's ``torch.stack``."""
+    chan = action[..., 0]
+    dosage = torch.max(chan, dim=0)[0]
+    hit = (chan != 0).t()
+    counts = hit.sum(dim=1)
+    k = int(counts[0]) if counts.numel() else 0
+    if counts.numel() and not bool((counts == k).all()):
+        raise RuntimeError("stack expects each tensor to be equal size (patients have different dose counts)")
+    return dosage, torch.nonzero(hit)[:, 1].reshape(hit.shape[0], k)
+
+
 class _RocheFixedGrid(torch.autograd.Function):
     """h = odeint(RocheODE, y0, t, method) on the gfx950 kernel; backward = discrete adjoint kernel."""
 

@@ -101,6 +101,9 @@ class EncoderLSTM(nn.Module, GaussianReparam):
         return mu, log_var
 
 
+dose_schedule_index = hode.solver.dose_schedule_index
+
+
 _THETA_FIELDS = sim_config.RochConfig._fields  # == parameter creation order of the reference (model.py:468-482)
 
 
@@ -138,15 +141,27 @@ class RocheODE(nn.Module):
     # -- dose schedule -------------------------------------------------------------------------------------
     def set_action(self, action):
         """dosage (B,) = max over time; times (B, K) = non-zero grid indices * step_size.  Vectorised: the
-        reference's per-patient Python loop (model.py:500-507) costs 0.19 s at 10k patients."""
-        chan = action[..., 0]
-        self.dosage = torch.max(chan, dim=0)[0]
-        hit = (chan != 0).t()
-        counts = hit.sum(dim=1)
-        k = int(counts[0]) if counts.numel() else 0
-        if counts.numel() and not bool((counts == k).all()):
-            raise RuntimeError("stack expects each tensor to be equal size (patients have different dose counts)")
-        self.times = torch.nonzero(hit)[:, 1].reshape(hit.shape[0], k) * self.step_size
+        reference's per-patient Python loop (model.py:500-507) costs 0.19 s at 10k patients.
+
+        Finding the dose indices needs the dose count K on the host (one device read-back + ``nonzero``): three host
+        synchronisations in the middle of a training step, behind which the host has to enqueue the rest of the step while
+        the GPU waits (bench.py ``full_training_step.host_enqueue_ms``).  Two sync-free routes: a batch source that knows
+        its data (``hode.batches.DeviceFolds``) attaches the precomputed schedule to the action tensor
+        (``action.hode_schedule = (dosage, dose_index)``), and a tensor that was analysed before and has not been written to
+        since (same storage, same version counter) reuses its result."""
+        sched = getattr(action, "hode_schedule", None)
+        if sched is not None:
+            self.dosage, idx = sched
+            self.times = idx * self.step_size
+            return
+        key = (action.data_ptr(), action._version, tuple(action.shape), action.device)
+        cached = getattr(self, "_schedule_cache", None)
+        if cached is not None and cached[0] == key:
+            self.dosage, self.times = cached[1], cached[2] * self.step_size
+            return
+        dosage, idx = dose_schedule_index(action)
+        self.dosage, self.times = dosage, idx * self.step_size
+        self._schedule_cache = (key, dosage, idx)
 
     def dose_at_time(self, t):
         on = t >= self.times
@@ -387,7 +402,13 @@ class RocheODEReal(nn.Module):
         if step_size is not None and t.numel() > 1:
             # torchdiffeq builds its own grid t0 + k*step_size; when that IS the output grid (run_real.py's default,
             # ode_step_div = 1) nothing has to be interpolated
-            if torch.allclose(t[1:] - t[:-1], torch.full_like(t[1:], float(step_size))):
+            # (a host read-back: cached per grid tensor, the decoder hands over the same `t` at every call)
+            key = (t.data_ptr(), t._version, t.numel(), float(step_size))
+            cache = getattr(self, "_uniform_grid_cache", None)
+            if cache is None or cache[0] != key:
+                cache = (key, bool(torch.allclose(t[1:] - t[:-1], torch.full_like(t[1:], float(step_size)))))
+                self._uniform_grid_cache = cache
+            if cache[1]:
                 step_size = None
         options.pop("step_t", None)  # ignored by fixed-grid solvers (torchdiffeq only warns)
         theta = torch.stack([self.k_immunity, self.kel, self.kel2])

@@ -72,3 +72,52 @@ def test_synthetic_folds_have_the_benchmark_distribution():
     chan = f.actions[..., 0]
     assert bool(((chan != 0).sum(dim=0) == 1).all()) and bool((chan[-1] == 0).all()) and float(chan.max()) <= 10.01
     assert 0.4 < float(f.masks.mean()) < 0.6 and abs(float(f.latents[0].mean()) - 0.01) < 2e-3
+
+
+def test_batches_carry_their_dose_schedule_and_set_action_uses_it():
+    """`DeviceFolds` derives a fold's dose schedule once and attaches the batch's gather of it to the action tensor;
+    `RocheODE.set_action` then needs no host synchronisation (reference model.py:495-507 loops over the patients).  The
+    attached schedule must be what set_action derives from the tensor itself, for random minibatches, fixed chunks and
+    the whole fold; a tensor analysed before and not written since is served from the identity cache, a written one is not."""
+    import model
+    from hode.batches import DeviceFolds
+    cpu = torch.device("cpu")
+    folds = DeviceFolds.synthetic(60, 12, 6, 8, 10, 10, cpu, seed=3)
+    ode = model.RocheODE(8, 1, 11 * 0.125, 0.125, device=cpu)
+    np.random.seed(1)
+    for batch in (folds.get_mini_batch("train", 16), folds.get_split("train", 16, 1), folds.get_split("val", 10, 0)):
+        a = batch["actions"]
+        assert hasattr(a, "hode_schedule")
+        ode.set_action(a)
+        dosage, times = ode.dosage.clone(), ode.times.clone()
+        ode.set_action(a.clone())            # a plain tensor: the reference's derivation
+        assert torch.equal(ode.dosage, dosage) and torch.equal(ode.times, times) and times.dtype == torch.float32
+    # identity cache
+    a = folds.get_split("train", 16, 0)["actions"].clone()
+    calls = {"n": 0}
+    inner = model.hode.solver.dose_schedule_index
+    def counted(x):
+        calls["n"] += 1
+        return inner(x)
+    model.dose_schedule_index = counted
+    try:
+        ode.set_action(a); ode.set_action(a)
+        assert calls["n"] == 1
+        t_dose = int(a[:, 0, 0].nonzero()[0])
+        a[t_dose, 0, 0] *= 2.0              # in-place write bumps the version counter: the cache must not serve it
+        ode.set_action(a)
+        assert calls["n"] == 2 and float(ode.dosage[0]) == float(a[t_dose, 0, 0])
+    finally:
+        model.dose_schedule_index = inner
+
+
+def test_shards_keep_the_dose_schedule():
+    from hode.batches import DeviceFolds
+    from hode.parallel import shard_batch
+    folds = DeviceFolds.synthetic(40, 10, 4, 8, 8, 8, torch.device("cpu"), seed=5)
+    batch = folds.get_split("train", 24, 0)
+    for rank in (0, 1, 2):
+        part = shard_batch(batch, rank, 3)
+        dosage, idx = part["actions"].hode_schedule
+        assert dosage.shape[0] == idx.shape[0] == part["actions"].shape[1] == 8
+        assert torch.equal(dosage, part["actions"][..., 0].max(dim=0)[0])
