@@ -348,8 +348,8 @@ def full_training_step(dev, iters=10, cpu=True, n_cpu=1000, dist=None, rank=0):
                         "encoder_fwd_bwd_ms": ms_enc,
                         "per_kernel": pieces,
                         "per_kernel_note": "HIP events on the launch stream around each piece of the encoder call: lstm_fwd = weight pack "
-                                           "kernels + lstm_fwd_kernel; lstm_bwd = lstm_bwd_kernel; wgrad_gemm = x*mask operand fill + "
-                                           "split-K hipBLASLt GEMM + fold; frac = executed flops / time / 157.3 TFLOP/s",
+                                           "kernels + lstm_fwd_kernel; lstm_bwd = lstm_bwd_kernel with the x*mask operand fill running beside it on a side "
+                                           "stream (2.73 ms alone); wgrad_gemm = split-K hipBLASLt GEMM + fold; frac = executed flops / time / 157.3 TFLOP/s",
                         "frac_of_whole_step": fl["total"] / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}}
     pm = lstm_pmc()
     if pm is not None and all(k in pm for k in ("lstm_fwd", "lstm_bwd", "wgrad_gemm")):

@@ -96,6 +96,17 @@ def _splitk_tn(lhs, rhs):
     return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2]).t()
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One side stream per device for work that is independent of the kernel on the current stream."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class _LstmEncode(torch.autograd.Function):
     """h_final = LSTM(window); backward = BPTT kernel + one split-K BLAS GEMM over K = T*B for all weight and bias gradients."""
 
@@ -141,14 +152,29 @@ class _LstmEncode(torch.autograd.Function):
         d.h_out, d.c_out = h_dummy.data_ptr(), h_dummy.data_ptr()  # unused by the backward, must be non-NULL
         d.grad_h_out, d.grad_gates, d.h_prev = gh.data_ptr(), dgates.data_ptr(), hprev.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        with torch.cuda.device(xc.device), _Span("lstm_bwd"):
-            L.check(lib.hode_lstm_bwd(d, _stream()), "hode_lstm_bwd")
-        dg2 = dgates.view(T * B, 4 * H)
-        with _Span("wgrad_gemm"):
+        # The first obs columns of the operand rows (x * mask) do not depend on the recurrence: they are filled on a side stream
+        # WHILE the BPTT kernel runs (it occupies 209 of the 256 CUs at the bench shape and is bound by the matrix pipe, the fill
+        # by HBM: 0.26 ms off the critical path; HODE_LSTM_SERIAL_FILL=1 keeps it behind the kernel for A/Bs).
+        side = None if os.environ.get("HODE_LSTM_SERIAL_FILL") else _side_stream(xc.device)
+
+        def fill():
             if mc is not None:
                 torch.mul(xc, mc, out=hprev[:, :, :obs])   # the kernel leaves the first obs columns to the caller
             else:
                 hprev[:, :, :obs].copy_(xc)
+
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())     # hprev's allocation and whatever produced x / mask
+            with torch.cuda.stream(side):
+                fill()
+        with torch.cuda.device(xc.device), _Span("lstm_bwd"):
+            L.check(lib.hode_lstm_bwd(d, _stream()), "hode_lstm_bwd")
+        dg2 = dgates.view(T * B, 4 * H)
+        with _Span("wgrad_gemm"):
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                fill()
             g = _splitk_tn(dg2, hprev.view(T * B, W))  # ONE product: [grad_w_ih | grad_w_hh | grad_b | 0]
         g_wih = g[:, :I].contiguous()
         g_whh = g[:, I:I + H].contiguous()
