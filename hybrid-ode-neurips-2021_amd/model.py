@@ -147,21 +147,21 @@ class RocheODE(nn.Module):
         synchronisations in the middle of a training step, behind which the host has to enqueue the rest of the step while
         the GPU waits (bench.py ``full_training_step.host_enqueue_ms``).  Two sync-free routes: a batch source that knows
         its data (``hode.batches.DeviceFolds``) attaches the precomputed schedule to the action tensor
-        (``action.hode_schedule = (dosage, dose_index)``), and a tensor that was analysed before and has not been written to
-        since (same storage, same version counter) reuses its result."""
+        (``action.hode_schedule = (dosage, dose_index)``), and a tensor OBJECT that was analysed before and has not been written to
+        since (same object, same version counter) reuses its result."""
         sched = getattr(action, "hode_schedule", None)
         if sched is not None:
             self.dosage, idx = sched
             self.times = idx * self.step_size
             return
-        key = (action.data_ptr(), action._version, tuple(action.shape), action.device)
+        # identity, not address: the cache keeps the tensor alive, so its storage cannot be recycled for another batch
         cached = getattr(self, "_schedule_cache", None)
-        if cached is not None and cached[0] == key:
-            self.dosage, self.times = cached[1], cached[2] * self.step_size
+        if cached is not None and cached[0] is action and cached[1] == action._version:
+            self.dosage, self.times = cached[2], cached[3] * self.step_size
             return
         dosage, idx = dose_schedule_index(action)
         self.dosage, self.times = dosage, idx * self.step_size
-        self._schedule_cache = (key, dosage, idx)
+        self._schedule_cache = (action, action._version, dosage, idx)
 
     def dose_at_time(self, t):
         on = t >= self.times
@@ -403,12 +403,11 @@ class RocheODEReal(nn.Module):
             # torchdiffeq builds its own grid t0 + k*step_size; when that IS the output grid (run_real.py's default,
             # ode_step_div = 1) nothing has to be interpolated
             # (a host read-back: cached per grid tensor, the decoder hands over the same `t` at every call)
-            key = (t.data_ptr(), t._version, t.numel(), float(step_size))
             cache = getattr(self, "_uniform_grid_cache", None)
-            if cache is None or cache[0] != key:
-                cache = (key, bool(torch.allclose(t[1:] - t[:-1], torch.full_like(t[1:], float(step_size)))))
+            if cache is None or cache[0] is not t or cache[1] != (t._version, float(step_size)):
+                cache = (t, (t._version, float(step_size)), bool(torch.allclose(t[1:] - t[:-1], torch.full_like(t[1:], float(step_size)))))
                 self._uniform_grid_cache = cache
-            if cache[1]:
+            if cache[2]:
                 step_size = None
         options.pop("step_t", None)  # ignored by fixed-grid solvers (torchdiffeq only warns)
         theta = torch.stack([self.k_immunity, self.kel, self.kel2])

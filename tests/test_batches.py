@@ -103,6 +103,13 @@ def test_batches_carry_their_dose_schedule_and_set_action_uses_it():
     try:
         ode.set_action(a); ode.set_action(a)
         assert calls["n"] == 1
+        b2 = a.clone()                      # an equal tensor that is another object (e.g. a recycled address): not served
+        ode.set_action(b2)
+        assert calls["n"] == 2
+        ode.set_action(a)
+        calls["n"] = 1
+        ode.set_action(a)                   # (a is cached again now)
+        assert calls["n"] == 1
         t_dose = int(a[:, 0, 0].nonzero()[0])
         a[t_dose, 0, 0] *= 2.0              # in-place write bumps the version counter: the cache must not serve it
         ode.set_action(a)
