@@ -44,6 +44,9 @@
 
 namespace hode {
 
+#ifndef HODE_SPLIT_EXPERT_FIRST
+#define HODE_SPLIT_EXPERT_FIRST 1   // bias + expert columns of tanh(W y + b) ahead of the stage chain (MlRows::rhs_expert); 0: A/B
+#endif
 constexpr int kSplitPatients = 48;  // per workgroup: wave 0 holds all 48 (one per lane), waves 1..3 hold 16 each
 
 struct SplitArgs {
@@ -231,6 +234,39 @@ struct MlRows {
       return tanh_scaled(hsum(acc));
     }
   }
+  // rhs split at the expert columns: the expert stage states of ALL stages of a step are known when the step starts (the
+  // expert wave publishes them one step ahead), the learned components only stage by stage.  rhs_expert() forms the first
+  // links of the accumulator chains -- bias and columns 0..3, in the order rhs() takes them -- off the stage-to-stage
+  // dependency chain; rhs_rest() continues with the learned columns.  Same operations in the same order as rhs(): the result
+  // is bit-identical, the chain through a stage is two packed fmas shorter.
+  struct Part { f2 a, b; };
+  HODE_DEV Part rhs_expert(const float4& e) const {
+    Part p;
+    if constexpr (MR == 2) {
+      p.a = vfma(wp[2], e.z, vfma(wp[0], e.x, bias));
+      p.b = vfma(wp[3], e.w, vfma(wp[1], e.y, splat2(0.f)));
+    } else {
+      p.a = vfma(wp[1], pair2(e.z, e.w), vfma(wp[0], pair2(e.x, e.y), pair2(bias, 0.f)));
+      p.b = splat2(0.f);
+    }
+    return p;
+  }
+  HODE_DEV Own rhs_rest(const Part& p, const Stage& Y) const {
+    if constexpr (MR == 2) {
+      f2 acc = p.a, acc1 = p.b;
+#pragma unroll
+      for (int i = 4; i < D; i += 2) {
+        acc = vfma(wp[i], Y.v[i], acc);
+        acc1 = vfma(wp[i + 1], Y.v[i + 1], acc1);
+      }
+      return tanh_scaled(acc + acc1);
+    } else {
+      f2 acc = p.a;
+#pragma unroll
+      for (int ip = 2; ip < DP; ++ip) acc = vfma(wp[ip], Y.v[ip], acc);
+      return tanh_scaled(hsum(acc));
+    }
+  }
   // dw += u (x) Y in the layout of wp
   static HODE_DEV void outer_acc(f2 (&dw)[NW], Own u, const Stage& Y) {
 #pragma unroll
@@ -413,12 +449,21 @@ HODE_DEV void split_fwd_body(const SplitArgs& a) {
       __builtin_amdgcn_sched_barrier(0);  // keep the four reads here: the scheduler would sink each next to its use
       // the expert wave is at step `it` now and reads dring[it & 1]; past the last step this writes an unread slot
       dose_step(par, t_c, t_d);
+#if HODE_SPLIT_EXPERT_FIRST
+      typename Ml::Part pe[4];   // bias + expert columns of every stage, ahead of the stage chain (MlRows::rhs_expert)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) pe[s] = ml.rhs_expert(e[s]);
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) k[s] = vsplat<Own>(0.f);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const Own Yo = sp_stage_state<METHOD>(s, yo, dt, k[0], k[1], k[2]);
+#if HODE_SPLIT_EXPERT_FIRST
+        k[s] = ml.rhs_rest(pe[s], Ml::stage(e[s], Yo));
+#else
         k[s] = ml.rhs(Ml::stage(e[s], Yo));
+#endif
       }
       yo = sp_advance<METHOD>(yo, dt, k[0], k[1], k[2], k[3]);
       // no `if (live)`: a quad beyond the batch integrates a bit-identical copy of patient B-1 (p is clamped) and
@@ -926,6 +971,11 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh)
           dring[par][slot][q] = dq.v;
           if constexpr (NEED_TH) dring[par][slot][4 + q] = dq.dk;
         }
+#if HODE_SPLIT_EXPERT_FIRST
+        typename Ml::Part pe[4];
+#pragma unroll
+        for (int s = 0; s < NS - NLT; ++s) pe[s] = ml.rhs_expert(e[s]);
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) so[s] = vsplat<Own>(0.f);
 #pragma unroll
@@ -933,7 +983,11 @@ HODE_DEV void split_bwd_body(const SplitBwdArgs& a, SplitBwdShared<D, TAPE>& sh)
           const Own Yo = sp_stage_state<METHOD>(s, yo, dt, so[0], so[1], so[2]);
           Y[s] = Ml::stage(e[s], Yo);
           if (s >= NS - NLT) so[s] = lt[s - (NS - NLT) < 0 ? 0 : s - (NS - NLT)];  // what the forward computed, bit for bit
+#if HODE_SPLIT_EXPERT_FIRST
+          else so[s] = ml.rhs_rest(pe[s], Y[s]);
+#else
           else so[s] = ml.rhs(Y[s]);
+#endif
         }
         // ---- adjoint of the stages
         HODE_PSTAMP(k, 2)
