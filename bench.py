@@ -196,6 +196,12 @@ def cpu_baseline_and_parity(prob, gpu, warm=3, reps=5):
     return base, par
 
 
+def _profile_order(path):
+    """Natural order of the committed profile names (r03_v10 after r03_v9): the newest set wins."""
+    import re
+    return [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(path))]
+
+
 def pmc_traffic(tape=True):
     """HBM bytes per launch of the dominant (backward) kernel from the committed rocprofv3 --pmc passes
     (profiles/*_pmc_summary.json, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); None if absent.  The counters
@@ -203,7 +209,7 @@ def pmc_traffic(tape=True):
     timed (the JSON line says so in `traffic_source`)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), key=_profile_order):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
@@ -231,7 +237,7 @@ def lstm_pmc():
     (profiles/*lstm*_pmc_summary.json: FETCH_SIZE / WRITE_SIZE in separate passes, matrix-pipe busy cycles, LDS bank
     conflicts); None if absent.  Counters cannot be collected from inside this process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*lstm*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*lstm*_pmc_summary.json")), key=_profile_order)
     if not files:
         return None
     d = json.load(open(files[-1]))
