@@ -46,6 +46,30 @@ class GaussianReparam:
         return lp.sum(dim=-1)
 
 
+class _AnalyticKL(torch.autograd.Function):
+    """mean_b( -0.5 sum_d(1 + log_var - mu^2 - exp(log_var)) ) (model.py:1188) with a hand-written backward: 8 launches
+    instead of the 18 the expression and its autograd graph take -- on a (B, D) operand every one of them is launch latency."""
+
+    @staticmethod
+    def forward(ctx, mu, log_var):
+        e = torch.exp(log_var)
+        ctx.save_for_backward(mu, e)
+        B, D = mu.shape
+        return (torch.sum(torch.addcmul(log_var, mu, mu, value=-1.0) - e) + float(B * D)) * (-0.5 / B)
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, e = ctx.saved_tensors
+        c = g / mu.shape[0]
+        return c * mu, (e - 1.0) * (0.5 * c)
+
+
+def analytic_kl(mu, log_var):
+    if mu.is_cuda and mu.dim() == 2:
+        return _AnalyticKL.apply(mu, log_var)
+    return torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+
+
 class StandardNormalPrior:
     @staticmethod
     def log_density(z):
@@ -343,7 +367,7 @@ class RocheODEReal(nn.Module):
         self.action_dim, self.latent_dim = int(action_dim), int(latent_dim)
         self.static_dim, self.hidden_dim = int(static_dim), int(hidden_dim)
         self.dosage = None
-        self.times = None
+        self._times = None
         self.device = get_device() if device is None else device
         self.t_max, self.step_size = t_max, step_size
         h = self.hidden_dim
@@ -363,7 +387,19 @@ class RocheODEReal(nn.Module):
 
     def set_action_static(self, action, static):
         self.dosage = action
-        self.times = torch.cumsum(torch.ones_like(action), dim=0)
+        self._times = None
+
+    @property
+    def times(self):
+        """1, 2, .., T along the time axis, shaped like the action (model.py:650-651).  Only the eager rhs (`forward`,
+        `dose_at_time`) reads it -- the kernels index time themselves -- so it is formed on first use, not per step."""
+        if self._times is None and self.dosage is not None:
+            self._times = torch.cumsum(torch.ones_like(self.dosage), dim=0)
+        return self._times
+
+    @times.setter
+    def times(self, value):
+        self._times = value
 
     def dose_at_time(self, t):
         on = t >= self.times
@@ -540,7 +576,7 @@ class VariationalInference:
         if not self.elbo:
             return lik
         if self.prior_log_pdf is None:
-            kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+            kld = analytic_kl(mu, log_var)
         else:
             kld = torch.mean(self.mc_kl(mu, log_var, self.mc_size), dim=0)
         return lik + kld
@@ -584,8 +620,7 @@ class VariationalInferenceReal(VariationalInference):
     def loss(self, data):
         x, a, mask, s = data["measurements"], data["actions"], data["masks"], data["statics"]
         t0 = self.t0
-        a_in = torch.cat([a, s], dim=-1)
-        mu, log_var = self.encoder(x[:t0], a_in[:t0], mask[:t0])
+        mu, log_var = self.encoder(x[:t0], torch.cat([a[:t0], s[:t0]], dim=-1), mask[:t0])   # only the window is assembled
         z = self.encoder.reparameterize(mu, log_var) if self.elbo else mu
         self.z = z
         fused = getattr(self.decoder, "fused_likelihood_ok", None)
@@ -606,7 +641,7 @@ class VariationalInferenceReal(VariationalInference):
         if not self.elbo:
             return lik
         if self.prior_log_pdf is None:
-            kld = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+            kld = analytic_kl(mu, log_var)
         else:
             kld = torch.mean(self.mc_kl(mu, log_var, self.mc_size), dim=0)
         return lik + kld

@@ -239,3 +239,20 @@ def test_dopri5_under_no_grad_with_parameters_takes_the_tape_less_path(roche, D)
     assert st_eval["workspace_bytes"] <= 24 * (1 << 20) + 64 * B * D * 4 + (1 << 16), st_eval
     assert st_eval["n_accepted"] == st_grad["n_accepted"] and st_eval["n_rejected"] == st_grad["n_rejected"]
     assert torch.equal(h_grad.detach(), h_eval)
+
+
+def test_analytic_kl_function_matches_the_reference_expression():
+    """model.analytic_kl (hand-written backward, fewer launches) against the expression of model.py:1188 in fp64."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    mu = torch.randn(1000, 12, generator=g).to(dev).requires_grad_(True)
+    lv = (0.5 * torch.randn(1000, 12, generator=g)).to(dev).requires_grad_(True)
+    out = model.analytic_kl(mu, lv)
+    gm, gl = torch.autograd.grad(3.0 * out, (mu, lv))
+    mu64, lv64 = mu.detach().double().requires_grad_(True), lv.detach().double().requires_grad_(True)
+    assert isinstance(out.grad_fn, torch.autograd.function.BackwardCFunction)   # the fused function ran, not the expression
+    ref = torch.mean(-0.5 * torch.sum(1 + lv64 - mu64 ** 2 - lv64.exp(), dim=1), dim=0)
+    rm, rl = torch.autograd.grad(3.0 * ref, (mu64, lv64))
+    assert abs(out.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    assert (gm.double() - rm).abs().max().item() <= 1e-6 * rm.abs().max().item()
+    assert (gl.double() - rl).abs().max().item() <= 1e-6 * rl.abs().max().item()

@@ -30,4 +30,4 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(3): step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=110))
