@@ -256,3 +256,15 @@ def test_analytic_kl_function_matches_the_reference_expression():
     assert abs(out.item() - ref.item()) <= 1e-6 * abs(ref.item())
     assert (gm.double() - rm).abs().max().item() <= 1e-6 * rm.abs().max().item()
     assert (gl.double() - rl).abs().max().item() <= 1e-6 * rl.abs().max().item()
+
+
+@pytest.mark.parametrize("rows,n,k", [(8192, 45, 44), (10000, 12, 160), (997, 20, 21)])
+def test_split_weight_gradient_product_matches_fp64(rows, n, k):
+    """model._rows_tn (the heads' weight gradient as a batched product over row slices) against g.T @ x in fp64."""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(rows)
+    g, x = torch.randn(rows, n, generator=gen).to(dev), torch.randn(rows, k, generator=gen).to(dev)
+    out = model._rows_tn(g, x)
+    ref = g.double().t() @ x.double()
+    assert out.shape == (n, k)
+    assert _rel(out, ref) <= 2e-6
