@@ -72,6 +72,17 @@ def lstm_final_state(x, a, mask, w_ih, w_hh, b_ih, b_hh, reverse=True):
     return h, c
 
 
+_ONES = {}
+
+
+def _ones_row(n, like):
+    """(1 x n) all-ones GEMM operand, kept per (n, device, dtype): a fill kernel per use is pure launch latency."""
+    key = (n, like.device, like.dtype)
+    if key not in _ONES:
+        _ONES[key] = torch.ones((1, n), device=like.device, dtype=like.dtype)
+    return _ONES[key]
+
+
 def _splitk_tn(lhs, rhs):
     """lhs^T @ rhs for tall operands (K x M, K x N with K ~ 1e6, M, N ~ 1e2): the BLAS heuristics pick a kernel without
     split-K for this shape (2.4-3.5 ms measured); batching K into P slices and summing runs 2x faster (tools/gemm_probe.py)."""
@@ -88,12 +99,10 @@ def _splitk_tn(lhs, rhs):
     # (tools/gemm_orient_probe.py), 0.05 ms inside the training step (same-call A/B, HODE_LSTM_GEMM_MN=1)
     if os.environ.get("HODE_LSTM_GEMM_MN"):   # A/B switch: the product in its natural orientation
         part = torch.bmm(lhs.view(P, K // P, -1).transpose(1, 2), rhs.view(P, K // P, -1))
-        ones = torch.ones((1, P), device=part.device, dtype=part.dtype)
-        return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2])
+        return (_ones_row(P, part) @ part.view(P, -1)).view(part.shape[1], part.shape[2])
     part = torch.bmm(rhs.view(P, K // P, -1).transpose(1, 2), lhs.view(P, K // P, -1))
     # fold the P partial products with a (1 x P) GEMM: torch's strided sum(0) over this shape reads at ~0.3 TB/s
-    ones = torch.ones((1, P), device=part.device, dtype=part.dtype)
-    return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2]).t()
+    return (_ones_row(P, part) @ part.view(P, -1)).view(part.shape[1], part.shape[2]).t()
 
 
 _SIDE = {}

@@ -473,8 +473,36 @@ class _TallLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
-        ones = torch.ones((1, g.shape[0]), device=g.device, dtype=g.dtype)
-        return g @ weight, _rows_tn(g, x), (ones @ g).reshape(-1)
+        return g @ weight, _rows_tn(g, x), _rows_sum(g)
+
+
+_ONES = {}
+
+
+def _ones(*shape, like):
+    """Constant all-ones GEMM operand, kept per (shape, device, dtype): a fill kernel per use is 5 us of launch latency."""
+    key = (shape, like.device, like.dtype)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(shape, device=like.device, dtype=like.dtype)
+    return _ONES[key]
+
+
+def _row_slices(t):
+    rows = t.shape[0]
+    if t.is_cuda:
+        for cand in range(64, 1, -1):
+            if rows % cand == 0 and rows // cand >= 128:
+                return cand
+    return 1
+
+
+def _rows_sum(g):
+    """Column sums of a (rows x n) matrix as GEMMs with a ones vector, over row slices like `_rows_tn`."""
+    rows, P = g.shape[0], _row_slices(g)
+    if P == 1:
+        return (_ones(1, rows, like=g) @ g).reshape(-1)
+    part = torch.bmm(_ones(P, 1, rows // P, like=g), g.view(P, rows // P, -1))
+    return (_ones(1, P, like=g) @ part.view(P, -1)).reshape(-1)
 
 
 def _rows_tn(g, x):
@@ -482,18 +510,11 @@ def _rows_tn(g, x):
     tiles, so the library runs the whole contraction on as many workgroups (57 us for 45 x 44 over 8 192 rows, config 5's
     encoder heads).  The rows are cut into P slices, one batched product forms P partial results on P times as many
     workgroups and a (1 x P) product folds them."""
-    rows = g.shape[0]
-    P = 1
-    if g.is_cuda:
-        for cand in range(64, 1, -1):
-            if rows % cand == 0 and rows // cand >= 128:
-                P = cand
-                break
+    rows, P = g.shape[0], _row_slices(g)
     if P == 1:
         return g.t() @ x
     part = torch.bmm(g.view(P, rows // P, -1).transpose(1, 2), x.view(P, rows // P, -1))
-    ones = torch.ones((1, P), device=g.device, dtype=g.dtype)
-    return (ones @ part.view(P, -1)).view(part.shape[1], part.shape[2])
+    return (_ones(1, P, like=g) @ part.view(P, -1)).view(part.shape[1], part.shape[2])
 
 
 def _tall_mlp(seq, x):
@@ -555,7 +576,7 @@ class DecoderReal(nn.Module):
         HBM; the two Linear layers, the ELU, the loss and all their gradients are one kernel)."""
         from hode import readout
         l0, l2 = self.output_function[0], self.output_function[2]
-        return readout.masked_sse_readout_mlp(h[1:], x, mask, l0.weight, l0.bias, l2.weight, l2.bias, time_weight)
+        return readout.masked_sse_readout_mlp(h, x, mask, l0.weight, l0.bias, l2.weight, l2.bias, time_weight, skip_rows=1)
 
 
 class VariationalInference:

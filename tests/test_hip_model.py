@@ -268,3 +268,11 @@ def test_split_weight_gradient_product_matches_fp64(rows, n, k):
     ref = g.double().t() @ x.double()
     assert out.shape == (n, k)
     assert _rel(out, ref) <= 2e-6
+
+
+def test_split_column_sum_matches_fp64():
+    dev = _dev()
+    g = torch.randn(8192, 45, generator=torch.Generator().manual_seed(3)).to(dev)
+    assert _rel(model._rows_sum(g), g.double().sum(dim=0)) <= 2e-6
+    g = torch.randn(997, 20, generator=torch.Generator().manual_seed(4)).to(dev)
+    assert _rel(model._rows_sum(g), g.double().sum(dim=0)) <= 2e-6

@@ -138,6 +138,33 @@ def test_mlp_readout_loss_and_gradients(D, T, B, weighted):
     assert abs(lik2.item() - lik.item()) <= 1e-6 * abs(lik.item())
 
 
+@pytest.mark.parametrize("D,B", [(20, 33), (4, 17), (20, 257)])
+def test_mlp_readout_skip_rows_equals_slicing(D, B):
+    """skip_rows=1 (DecoderReal: the state at t0 - 1 is not read out) gives the same loss and gradients as passing h[1:]:
+    bit for bit, with an exactly zero gradient row 0.  (4, 17): 68 floats per row -- aligned; the unaligned case falls back
+    to slicing and is covered by the equality itself.)"""
+    from hode.readout import masked_sse_readout_mlp
+    dev = _dev()
+    T, obs = 6, 24
+    gen = torch.Generator().manual_seed(100 + B)
+    h = torch.randn(T + 1, B, D, generator=gen).to(dev)
+    x = torch.randn(T, B, obs, generator=gen).to(dev)
+    m = (torch.rand(T, B, obs, generator=gen) < 0.5).float().to(dev)
+    torch.manual_seed(D)
+    net = torch.nn.Sequential(torch.nn.Linear(D, D + 1), torch.nn.ELU(), torch.nn.Linear(D + 1, obs)).to(dev)
+    tw = (1 / torch.arange(1, T + 1, dtype=torch.float32)).to(dev)
+    outs = []
+    for skip in (True, False):
+        hg = h.clone().requires_grad_(True)
+        prm = [p.detach().clone().requires_grad_(True) for p in (net[0].weight, net[0].bias, net[2].weight, net[2].bias)]
+        lik = masked_sse_readout_mlp(hg, x, m, *prm, tw, skip_rows=1) if skip else masked_sse_readout_mlp(hg[1:], x, m, *prm, tw)
+        (0.7 * lik).backward()
+        outs.append([lik.detach(), hg.grad] + [p.grad for p in prm])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert not outs[0][1][0].any()
+
+
 def test_real_vi_loss_uses_fused_mlp_readout_and_matches_unfused():
     import model
     dev = _dev()
