@@ -175,6 +175,10 @@ extern "C" int hode_lstm_fwd(const hode_lstm_desc* d, void* stream) {
   a.x = d->x; a.a = d->a; a.mask = d->mask; a.wp = wp; a.h_out = d->h_out; a.c_out = d->c_out; a.tape = tape;
   a.T = d->seq_len; a.B = d->batch; a.OBS = d->obs_dim; a.AD = d->input_dim - d->obs_dim; a.I = d->input_dim;
   a.H = d->hidden_dim; a.Hp = G.Hp; a.Kq = G.Kq; a.KQ4 = G.KQ4; a.LD = G.LD; a.reverse = d->reverse;
+  // tape runs: the x*mask columns of the backward's GEMM operand rows, if the caller hands the buffer over already
+  a.xm_out = d->save_tape ? d->h_prev : nullptr;
+  a.W = (d->input_dim + d->hidden_dim + 1 + 3) / 4 * 4;
+  if (a.xm_out && ((uintptr_t)a.xm_out & 15)) return hode::fail(HODE_E_ALIGN, "h_prev must be 16-byte aligned");
 #ifdef HODE_LSTM_STAMPS
   if (const char* env = getenv("HODE_LSTM_FWD_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(env, nullptr, 0);
 #endif

@@ -180,9 +180,11 @@ typedef struct hode_lstm_desc {
   const float* grad_h_out; /* [B][H] cotangent of h_out */
   float* grad_gates;   /* out [T][B][4H]: d loss / d pre-activation gates per step (feeds the weight-gradient GEMMs) */
   float* h_prev;       /* out: the weight-gradient GEMM operand [T][B][W], W = roundup4(I + H + 1), per (t, b) row:
-                          obs_dim columns LEFT UNTOUCHED for the caller's x*mask | action columns (I - obs_dim) | hidden
-                          state entering the step (H) | 1 | 0...   grad_gates^T h_prev over K = T*B then is
-                          [grad_w_ih | grad_w_hh | grad_b_ih = grad_b_hh | 0] */
+                          x*mask (obs_dim columns) | action columns (I - obs_dim) | hidden state entering the step (H) |
+                          1 | 0...   grad_gates^T h_prev over K = T*B then is [grad_w_ih | grad_w_hh | grad_b_ih =
+                          grad_b_hh | 0].  hode_lstm_bwd writes every column but the first obs_dim.  Those are written
+                          by hode_lstm_fwd (save_tape = 1) when it is handed the same buffer (16-byte aligned; NULL =
+                          the caller fills them itself before the product). */
   void* workspace;     /* >= hode_lstm_workspace_bytes: packed weights (+ tape when save_tape) */
   size_t workspace_bytes;
 } hode_lstm_desc;
