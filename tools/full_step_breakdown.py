@@ -25,3 +25,11 @@ tot = sum(e.self_device_time_total for e in rows)
 print("total device time per step: %.3f ms" % (tot / 3e3))
 for e in rows[:22]:
     print("%8.1f us/step  x%-3d %s" % (e.self_device_time_total / 3, e.count // 3, e.key[:110]))
+if "--ops" in sys.argv:   # the framework-level view: which aten op (with operand shapes) each small launch belongs to
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        step()
+        torch.cuda.synchronize()
+    ops = [(e.self_device_time_total, e.key, e.count, str(e.input_shapes)[:120]) for e in prof.key_averages(group_by_input_shape=True)
+           if e.self_device_time_total > 0 and e.key.startswith("aten::")]
+    for r in sorted(ops, reverse=True)[:40]:
+        print("%8.1f us  %-26s x%-3d %s" % r)
