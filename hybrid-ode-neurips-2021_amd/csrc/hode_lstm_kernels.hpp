@@ -37,9 +37,6 @@ struct LstmArgs {
   float* __restrict__ h_out;
   float* __restrict__ c_out;
   float* __restrict__ tape;         // [T][nblk][Hp/16 (unit tile = wave * TPW + tile of the wave)][NT][5][64] or nullptr
-  float* __restrict__ xm_out;       // the backward's GEMM operand rows [T][B][W] or nullptr: the first OBS columns (x * mask) are
-                                    // written here, where the product is formed anyway (a separate pass over x and mask cost 0.25 ms)
-  int W;
   int T, B, OBS, AD, I, H, Hp, Kq, KQ4, LD, reverse;
   unsigned long long* dbg;  // HODE_LSTM_STAMPS builds only: [T][8] s_memtime stamps of wave 0 of block 0
 };
@@ -135,7 +132,6 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
     }
   };
   auto stage_x = [&](float* dst, int t) {
-    float* xm = p.xm_out ? p.xm_out + ((size_t)t * p.B + b0) * p.W : nullptr;   // operand rows of this tile's patients
     if constexpr (vec4) {
 #pragma unroll
       for (int j = 0; j < XPT / 4; ++j) {
@@ -143,13 +139,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
         const int b = idx % BT, i4 = idx / BT;
         if (i4 < Q4) {
           const bool live = b < nvalid;  // zeros for patients past the batch
-          f32x4 v;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            v[c] = live ? (has_mask ? xs[4 * j + c] * ms[4 * j + c] : xs[4 * j + c]) : 0.f;
-            dst[(4 * i4 + c) * LD + b] = v[c];
-          }
-          if (xm && live) *reinterpret_cast<f32x4*>(xm + (size_t)b * p.W + 4 * i4) = v;   // W % 4 == 0: 16-byte aligned
+          for (int c = 0; c < 4; ++c)
+            dst[(4 * i4 + c) * LD + b] = live ? (has_mask ? xs[4 * j + c] * ms[4 * j + c] : xs[4 * j + c]) : 0.f;
         }
       }
     } else {
@@ -158,9 +150,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmArgs p) {
         const int e = tid + NTHR * j;
         if (e < n_x) {
           const int b = e / p.OBS, i = e - b * p.OBS;
-          const float v = has_mask ? xs[j] * ms[j] : xs[j];
-          dst[i * LD + b] = v;
-          if (xm) xm[(size_t)b * p.W + i] = v;
+          dst[i * LD + b] = has_mask ? xs[j] * ms[j] : xs[j];
         }
       }
     }

@@ -133,6 +133,7 @@ EXPORTS = (
     ("hode_mc_kl_exponential", C.c_int, (C.POINTER(McKlDesc), C.c_void_p)),
     ("hode_lstm_fwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
     ("hode_lstm_bwd", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
+    ("hode_lstm_fill_operand", C.c_int, (C.POINTER(LstmDesc), C.c_void_p)),
 )
 
 _lib = None

@@ -105,6 +105,17 @@ def _splitk_tn(lhs, rhs):
     return (_ones_row(P, part) @ part.view(P, -1)).view(part.shape[1], part.shape[2]).t()
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One side stream per device for work that is independent of the kernel on the current stream."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class _LstmEncode(torch.autograd.Function):
     """h_final = LSTM(window); backward = BPTT kernel + one split-K BLAS GEMM over K = T*B for all weight and bias gradients."""
 
@@ -124,26 +135,16 @@ class _LstmEncode(torch.autograd.Function):
             L.check(lib.hode_lstm_fwd(d, _stream()), "hode_lstm_fwd")
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
-        # The weight-gradient GEMM's operand rows [x*mask | a | h_prev | 1 | 0-pad] are allocated HERE when a backward will follow:
-        # the forward kernel forms x*mask anyway and writes those columns on the way (a separate pass over x and mask beside the
-        # BPTT kernel cost 0.25 ms of a 9.5 ms step); the BPTT kernel fills the rest.
-        hprev = None
-        if any(ctx.needs_input_grad[3:7]):
-            T, obs = xc.shape[0], xc.shape[2]
-            W = (obs + (0 if ac is None else ac.shape[-1]) + H + 1 + 3) // 4 * 4
-            hprev = torch.empty((T, B, W), device=x.device, dtype=torch.float32)
-            d.h_prev = hprev.data_ptr()
         with torch.cuda.device(x.device), _Span("lstm_fwd"):
             L.check(lib.hode_lstm_fwd(d, _stream()), "hode_lstm_fwd")
-        ctx.save_for_backward(xc, ac if ac is not None else xc, mc if mc is not None else xc, wi, wh, bi, bh, ws,
-                              hprev if hprev is not None else ws)
-        ctx.flags = (ac is not None, mc is not None, bool(reverse), hprev is not None)
+        ctx.save_for_backward(xc, ac if ac is not None else xc, mc if mc is not None else xc, wi, wh, bi, bh, ws)
+        ctx.flags = (ac is not None, mc is not None, bool(reverse))
         return h
 
     @staticmethod
     def backward(ctx, grad_h):
-        xc, ac, mc, wi, wh, bi, bh, ws, hprev = ctx.saved_tensors
-        has_a, has_m, reverse, has_rows = ctx.flags
+        xc, ac, mc, wi, wh, bi, bh, ws = ctx.saved_tensors
+        has_a, has_m, reverse = ctx.flags
         ac = ac if has_a else None
         mc = mc if has_m else None
         lib = L.lib()
@@ -154,21 +155,33 @@ class _LstmEncode(torch.autograd.Function):
         ad = 0 if ac is None else ac.shape[-1]
         I = obs + ad
         W = (I + H + 1 + 3) // 4 * 4
-        if not has_rows:   # the forward ran without the operand rows (no parameter needed a gradient then): fill the x columns here
-            hprev = torch.empty((T, B, W), device=xc.device, dtype=torch.float32)  # [x*mask | a | h_prev | 1 | 0-pad]
-            if mc is not None:
-                torch.mul(xc, mc, out=hprev[:, :, :obs])
-            else:
-                hprev[:, :, :obs].copy_(xc)
+        hprev = torch.empty((T, B, W), device=xc.device, dtype=torch.float32)  # [x*mask | a | h_prev | 1 | 0-pad]
         d = _desc(xc, ac, mc, wi, wh, bi, bh, reverse, True)
         h_dummy = torch.empty(1, device=xc.device)
         d.h_out, d.c_out = h_dummy.data_ptr(), h_dummy.data_ptr()  # unused by the backward, must be non-NULL
         d.grad_h_out, d.grad_gates, d.h_prev = gh.data_ptr(), dgates.data_ptr(), hprev.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        # The first obs columns of the operand rows (x * mask) do not depend on the recurrence: they are filled on a side stream
+        # WHILE the BPTT kernel runs (it occupies 209 of the 256 CUs at the bench shape and is bound by the matrix pipe, the fill
+        # by HBM: off the critical path; HODE_LSTM_SERIAL_FILL=1 keeps it behind the kernel for A/Bs).
+        side = None if os.environ.get("HODE_LSTM_SERIAL_FILL") else _side_stream(xc.device)
+
+        def fill():   # the kernel leaves the first obs columns to the caller: x * mask, one streaming pass on the current stream
+            with torch.cuda.device(xc.device):
+                L.check(lib.hode_lstm_fill_operand(d, _stream()), "hode_lstm_fill_operand")
+
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())     # hprev's allocation and whatever produced x / mask
+            with torch.cuda.stream(side):
+                fill()
         with torch.cuda.device(xc.device), _Span("lstm_bwd"):
             L.check(lib.hode_lstm_bwd(d, _stream()), "hode_lstm_bwd")
         dg2 = dgates.view(T * B, 4 * H)
         with _Span("wgrad_gemm"):
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                fill()
             g = _splitk_tn(dg2, hprev.view(T * B, W))  # ONE product: [grad_w_ih | grad_w_hh | grad_b | 0]
         g_wih = g[:, :I].contiguous()
         g_whh = g[:, I:I + H].contiguous()

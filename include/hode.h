@@ -180,11 +180,9 @@ typedef struct hode_lstm_desc {
   const float* grad_h_out; /* [B][H] cotangent of h_out */
   float* grad_gates;   /* out [T][B][4H]: d loss / d pre-activation gates per step (feeds the weight-gradient GEMMs) */
   float* h_prev;       /* out: the weight-gradient GEMM operand [T][B][W], W = roundup4(I + H + 1), per (t, b) row:
-                          x*mask (obs_dim columns) | action columns (I - obs_dim) | hidden state entering the step (H) |
-                          1 | 0...   grad_gates^T h_prev over K = T*B then is [grad_w_ih | grad_w_hh | grad_b_ih =
-                          grad_b_hh | 0].  hode_lstm_bwd writes every column but the first obs_dim.  Those are written
-                          by hode_lstm_fwd (save_tape = 1) when it is handed the same buffer (16-byte aligned; NULL =
-                          the caller fills them itself before the product). */
+                          obs_dim columns LEFT UNTOUCHED for the caller's x*mask | action columns (I - obs_dim) | hidden
+                          state entering the step (H) | 1 | 0...   grad_gates^T h_prev over K = T*B then is
+                          [grad_w_ih | grad_w_hh | grad_b_ih = grad_b_hh | 0] */
   void* workspace;     /* >= hode_lstm_workspace_bytes: packed weights (+ tape when save_tape) */
   size_t workspace_bytes;
 } hode_lstm_desc;
@@ -342,6 +340,10 @@ int hode_mc_kl_exponential(const hode_mckl_desc* desc, void* hip_stream);
 
 int hode_lstm_fwd(const hode_lstm_desc* desc, void* hip_stream);
 int hode_lstm_bwd(const hode_lstm_desc* desc, void* hip_stream);
+/* h_prev[t][b][0 .. obs_dim) = x * mask (x when mask is NULL): the columns of the weight-gradient operand rows that
+ * hode_lstm_bwd leaves to the caller.  Independent of the recurrence: may run on another stream beside hode_lstm_bwd, before
+ * the product that reads h_prev.  Uses seq_len, batch, input_dim, hidden_dim, obs_dim, x, mask, h_prev of the descriptor. */
+int hode_lstm_fill_operand(const hode_lstm_desc* desc, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -153,3 +153,28 @@ def test_hidden_size_above_the_largest_kernel_is_a_configuration_error():
     with pytest.raises(hode.HodeConfigError, match="exceeds the largest compiled kernel"):
         lstm_final_state(x.to(dev), a.to(dev), m.to(dev), lstm.weight_ih_l0.to(dev), lstm.weight_hh_l0.to(dev),
                          lstm.bias_ih_l0.to(dev), lstm.bias_hh_l0.to(dev))
+
+
+@pytest.mark.parametrize("obs,ad,masked", [(80, 1, True), (24, 0, True), (37, 0, False), (80, 1, False), (6, 3, True)])
+def test_fill_operand_writes_x_times_mask_into_the_first_columns(obs, ad, masked):
+    """hode_lstm_fill_operand: h_prev[t][b][:obs] = x * mask (x without a mask), every other column untouched -- bit for bit
+    (one multiplication per element); 16-byte path (obs % 4 == 0) and the scalar one."""
+    from hode import _lib as L
+    from hode import lstm as hl
+    dev = _dev()
+    T, B, H = 5, 67, 32
+    g = torch.Generator().manual_seed(obs)
+    x = torch.randn(T, B, obs, generator=g).to(dev)
+    a = torch.randn(T, B, ad, generator=g).to(dev) if ad else None
+    m = (torch.rand(T, B, obs, generator=g) < 0.5).float().to(dev) if masked else None
+    w_ih, w_hh = torch.randn(4 * H, obs + ad).to(dev), torch.randn(4 * H, H).to(dev)
+    b = torch.zeros(4 * H, device=dev)
+    W = (obs + ad + H + 1 + 3) // 4 * 4
+    hp = torch.full((T, B, W), -7.0, device=dev)
+    d = hl._desc(x, a, m, w_ih, w_hh, b, b, True, True)
+    dummy = torch.empty(1, device=dev)
+    d.h_out, d.c_out, d.h_prev = dummy.data_ptr(), dummy.data_ptr(), hp.data_ptr()
+    L.check(L.lib().hode_lstm_fill_operand(d, hl._stream()), "hode_lstm_fill_operand")
+    torch.cuda.synchronize()
+    assert torch.equal(hp[:, :, :obs], x * m if masked else x)
+    assert bool((hp[:, :, obs:] == -7.0).all())
