@@ -501,7 +501,7 @@ def _rows_sum(g):
     rows, P = g.shape[0], _row_slices(g)
     if P == 1:
         return (_ones(1, rows, like=g) @ g).reshape(-1)
-    part = torch.bmm(_ones(P, 1, rows // P, like=g), g.view(P, rows // P, -1))
+    part = torch.bmm(_ones(P, 1, rows // P, like=g), g.reshape(P, rows // P, -1))
     return (_ones(1, P, like=g) @ part.view(P, -1)).reshape(-1)
 
 
@@ -513,7 +513,7 @@ def _rows_tn(g, x):
     rows, P = g.shape[0], _row_slices(g)
     if P == 1:
         return g.t() @ x
-    part = torch.bmm(g.view(P, rows // P, -1).transpose(1, 2), x.view(P, rows // P, -1))
+    part = torch.bmm(g.reshape(P, rows // P, -1).transpose(1, 2), x.reshape(P, rows // P, -1))   # reshape: x may be a strided view
     return (_ones(1, P, like=g) @ part.view(P, -1)).view(part.shape[1], part.shape[2])
 
 
