@@ -342,7 +342,8 @@ int hode_lstm_fwd(const hode_lstm_desc* desc, void* hip_stream);
 int hode_lstm_bwd(const hode_lstm_desc* desc, void* hip_stream);
 /* h_prev[t][b][0 .. obs_dim) = x * mask (x when mask is NULL): the columns of the weight-gradient operand rows that
  * hode_lstm_bwd leaves to the caller.  Independent of the recurrence: may run on another stream beside hode_lstm_bwd, before
- * the product that reads h_prev.  Uses seq_len, batch, input_dim, hidden_dim, obs_dim, x, mask, h_prev of the descriptor. */
+ * the product that reads h_prev.  Takes the descriptor of the hode_lstm_bwd call it belongs to (validated as a whole); reads
+ * seq_len, batch, input_dim, hidden_dim, obs_dim, x, mask and writes h_prev. */
 int hode_lstm_fill_operand(const hode_lstm_desc* desc, void* hip_stream);
 
 #ifdef __cplusplus
