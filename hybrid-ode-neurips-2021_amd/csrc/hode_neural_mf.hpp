@@ -21,6 +21,18 @@ struct NeuralMf {
   v4 bias1[HT];
   v4 bias2;
   int g, n;
+  // Both tanh layers take their argument pre-multiplied by 2 log2(e) (folded into W1, b1, W2, b2 as they are gathered):
+  // tanh(z) = 1 - 2 / (exp2(z') + 1) then is v_exp, add, v_rcp, fma with the add and the fma on packed pairs -- 3 issue slots
+  // per value instead of 5.  The transposed operands of the VJP (A3, A4) stay unscaled.
+  static constexpr float kTanhScale = 2.885390081777927f;
+  static HODE_DEV v4 tanh_scaled(const v4& z) {
+    // written on pairs: on the four-vector the compiler kept the additions scalar
+    const f2 e0 = pair2(__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])) + splat2(1.0f);
+    const f2 e1 = pair2(__builtin_amdgcn_exp2f(z[2]), __builtin_amdgcn_exp2f(z[3])) + splat2(1.0f);
+    const f2 t0 = __builtin_elementwise_fma(pair2(__builtin_amdgcn_rcpf(e0.x), __builtin_amdgcn_rcpf(e0.y)), splat2(-2.0f), splat2(1.0f));
+    const f2 t1 = __builtin_elementwise_fma(pair2(__builtin_amdgcn_rcpf(e1.x), __builtin_amdgcn_rcpf(e1.y)), splat2(-2.0f), splat2(1.0f));
+    return v4{t0.x, t0.y, t1.x, t1.y};
+  }
 
   HODE_DEV void load(const NeuralArgs& a, int lane) {
     g = lane >> 4;
@@ -35,19 +47,19 @@ struct NeuralMf {
         const int col = 4 * g + r;          // k index of this lane within chunk r
         const int hrow = 16 * i + m;        // A-row of hidden-sized products
         const int hcol = 16 * i + 4 * g + r;  // k index over the hidden axis
-        A1[i][r] = (hrow < HD && col <= D) ? W1[(size_t)hrow * (D + 1) + col] : 0.f;        // W1[16i+m][4g+r]
-        A2[i][r] = (m < D && hcol < HD) ? W2[(size_t)m * HD + hcol] : 0.f;                  // W2[m][16i+4g+r]
+        A1[i][r] = (hrow < HD && col <= D) ? kTanhScale * W1[(size_t)hrow * (D + 1) + col] : 0.f;   // W1[16i+m][4g+r]
+        A2[i][r] = (m < D && hcol < HD) ? kTanhScale * W2[(size_t)m * HD + hcol] : 0.f;             // W2[m][16i+4g+r]
         A3[i][r] = (hrow < HD && col < D) ? W2[(size_t)col * HD + hrow] : 0.f;              // W2^T[16i+m][4g+r]
         A4[i][r] = (hcol < HD && m <= D) ? W1[(size_t)hcol * (D + 1) + m] : 0.f;            // W1^T[m][16i+4g+r]
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * i + 4 * g + r;
-        bias1[i][r] = row < HD ? a.b1[row] : 0.f;
+        bias1[i][r] = row < HD ? kTanhScale * a.b1[row] : 0.f;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias2[r] = (4 * g + r) < D ? a.b2[4 * g + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bias2[r] = (4 * g + r) < D ? kTanhScale * a.b2[4 * g + r] : 0.f;
   }
 
   // hidden activations a1 = tanh(W1 e + b1) for the input tile e (tile i, register r <-> hidden unit 16i + 4g + r)
@@ -60,9 +72,7 @@ struct NeuralMf {
 #pragma unroll
       for (int i = 0; i < HT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[i][r], e[r], acc[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < HT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a1[i][r] = tanh_f32(acc[i][r]);
+    for (int i = 0; i < HT; ++i) a1[i] = tanh_scaled(acc[i]);
   }
 
   // k = f(e) = tanh(W2 a1 + b2); a1 is left for the caller (the fixed-grid adjoint holds it, the adaptive one recomputes it)
@@ -75,11 +85,7 @@ struct NeuralMf {
     for (int i = 0; i < HT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) z[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[i][r], a1[i][r], z[r], 0, 0, 0);
-    const v4 zs = (z[0] + z[1]) + (z[2] + z[3]);
-    v4 k;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) k[r] = tanh_f32(zs[r]);
-    return k;
+    return tanh_scaled((z[0] + z[1]) + (z[2] + z[3]));
   }
 
   // VJP at a stage with activations a1 and output k: returns (df/de)^T gk; u2, u1 are the pre-activation cotangents
@@ -94,9 +100,8 @@ struct NeuralMf {
 #pragma unroll
       for (int i = 0; i < HT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[i][r], u2[r], acc[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < HT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) u1[i][r] = acc[i][r] * __builtin_fmaf(-a1[i][r], a1[i][r], 1.0f);
+    for (int i = 0; i < HT; ++i)   // same two operations per value as before (fma, mul), on packed pairs
+      u1[i] = acc[i] * __builtin_elementwise_fma(-a1[i], a1[i], v4{1.0f, 1.0f, 1.0f, 1.0f});
     v4 z[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) z[r] = v4{0.f, 0.f, 0.f, 0.f};
