@@ -27,6 +27,16 @@ typedef float v4 __attribute__((ext_vector_type(4)));
 
 HODE_DEV v4 mfma4(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+constexpr float kTanhScale = 2.885390081777927f;   // 2 log2(e)
+// tanh(z) = 1 - 2 / (exp2(z') + 1) for z' = kTanhScale z, four values
+HODE_DEV v4 tanh_scaled4(const v4& z) {
+  const f2 e0 = pair2(__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])) + splat2(1.0f);
+  const f2 e1 = pair2(__builtin_amdgcn_exp2f(z[2]), __builtin_amdgcn_exp2f(z[3])) + splat2(1.0f);
+  const f2 t0 = __builtin_elementwise_fma(pair2(__builtin_amdgcn_rcpf(e0.x), __builtin_amdgcn_rcpf(e0.y)), splat2(-2.0f), splat2(1.0f));
+  const f2 t1 = __builtin_elementwise_fma(pair2(__builtin_amdgcn_rcpf(e1.x), __builtin_amdgcn_rcpf(e1.y)), splat2(-2.0f), splat2(1.0f));
+  return v4{t0.x, t0.y, t1.x, t1.y};
+}
+
 template <int HT>
 struct RealMf {
   static constexpr int M = 16;
@@ -51,10 +61,12 @@ struct RealMf {
 #pragma unroll
     for (int i = 0; i < HT; ++i) {
       const int j = 16 * i + m;  // hidden unit addressed as an A ROW
+      // the hidden layers' tanh takes its argument pre-multiplied by 2 log2(e) (kTanhScale, folded into W11 / W21 / b11 / b21 here):
+      // v_exp, add, v_rcp, fma per activation, the fma on pairs -- see NeuralMf::tanh_scaled
 #pragma unroll
-      for (int r = 0; r < 3; ++r) A1a[i][r] = (g == 0 && j < H) ? w.W11[3 * j + r] : 0.f;
+      for (int r = 0; r < 3; ++r) A1a[i][r] = (g == 0 && j < H) ? kTanhScale * w.W11[3 * j + r] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) A1b[i][r] = (g == 0 && j < H) ? w.W21[2 * j + r] : 0.f;
+      for (int r = 0; r < 2; ++r) A1b[i][r] = (g == 0 && j < H) ? kTanhScale * w.W21[2 * j + r] : 0.f;
       A3[i] = (g == 0 && j < H) ? w.w12[j] : 0.f;
       A3[HT + i] = (g == 0 && j < H) ? w.w22[j] : 0.f;
 #pragma unroll
@@ -64,8 +76,8 @@ struct RealMf {
         A2[HT + i][r] = (m == 1 && jc < H) ? w.w22[jc] : 0.f;
         A4[i][r] = (m < 3 && jc < H) ? w.W11[3 * jc + m] : 0.f;
         A4[HT + i][r] = (m < 2 && jc < H) ? w.W21[2 * jc + m] : 0.f;
-        b1[i][r] = jc < H ? w.b11[jc] : 0.f;
-        b1[HT + i][r] = jc < H ? w.b21[jc] : 0.f;
+        b1[i][r] = jc < H ? kTanhScale * w.b11[jc] : 0.f;
+        b1[HT + i][r] = jc < H ? kTanhScale * w.b21[jc] : 0.f;
       }
     }
 #pragma unroll
@@ -99,9 +111,7 @@ struct RealMf {
         if (r < 2) acc[HT + i] = mfma4(A1b[i][r < 2 ? r : 0], s.X[r], acc[HT + i]);
       }
 #pragma unroll
-    for (int i = 0; i < NT2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s.ah[i][r] = tanh_f32(acc[i][r]);
+    for (int i = 0; i < NT2; ++i) s.ah[i] = tanh_scaled4(acc[i]);
     v4 zz[4];
     zz[0] = b2;
     zz[1] = zz[2] = zz[3] = v4{0.f, 0.f, 0.f, 0.f};
@@ -148,9 +158,8 @@ struct RealMf {
       da[HT + i] = mfma4(A3[HT + i], u22, v4{0.f, 0.f, 0.f, 0.f});
     }
 #pragma unroll
-    for (int i = 0; i < NT2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) U1[i][r] = da[i][r] * __builtin_fmaf(-s.ah[i][r], s.ah[i][r], 1.0f);
+    for (int i = 0; i < NT2; ++i)   // the same two operations per value (fma, mul), on pairs
+      U1[i] = da[i] * __builtin_elementwise_fma(-s.ah[i], s.ah[i], v4{1.0f, 1.0f, 1.0f, 1.0f});
     v4 zz[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) zz[r] = v4{0.f, 0.f, 0.f, 0.f};
